@@ -1,0 +1,43 @@
+# Builds libthunderfft_hip.so (gfx950 kernels + C ABI), the CPU oracle and the C++ bench harness.
+# Everything is built in-tree; objects go to build/.
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+HIPFLAGS   ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-variable -Wno-unused-but-set-variable
+CC         ?= gcc
+
+CSRC       := fft_amd/csrc
+LIBDIR     := fft_amd/lib
+BUILD      := build
+
+KERNEL_SRCS := $(CSRC)/inst_f32_a.hip $(CSRC)/inst_f32_b.hip $(CSRC)/inst_f32_c.hip \
+               $(CSRC)/inst_f16.hip $(CSRC)/inst_bf16.hip $(CSRC)/tfft_c_api.hip
+KERNEL_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNEL_SRCS))
+KERNEL_HDRS := $(wildcard $(CSRC)/*.hpp) include/thunderfft_c.h
+
+LIB        := $(LIBDIR)/libthunderfft_hip.so
+ORACLE     := oracle/liboracle_dft.so
+BENCH      := bench/tfft_bench
+
+.PHONY: all lib oracle bench clean
+all: lib oracle bench
+lib: $(LIB)
+oracle: $(ORACLE)
+bench: $(BENCH)
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(KERNEL_HDRS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(KERNEL_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(KERNEL_OBJS)
+
+$(ORACLE): oracle/dft_oracle.c
+	$(CC) -O2 -fPIC -shared -o $@ $< -lm
+
+$(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh $(LIB)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ bench/tfft_bench.cpp \
+	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+clean:
+	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH)

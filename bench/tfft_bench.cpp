@@ -1,0 +1,254 @@
+// Bench harness in the shape of the reference's sample/bench (thunderfft/sample/bench/main.cu:28-83,
+// util/helper.h:122-202, baseline/baseline_cufft.cu:28-69): for every length it fills the input,
+// runs the library comparator (hipFFT here, cuFFT there), validates ThunderFFT_global against it
+// (max-abs complex error, separate validation and timing buffers), then times single launches with
+// events: one warm-up, the mean of `runs` launches. On top of the reference's milliseconds it
+// reports GFLOP/s (5 N log2 N), GB/s (one read + one write per point) and the fraction of 8 TB/s.
+//
+// Usage: tfft_bench [--n 256,4096] [--points 268435456] [--runs 10] [--input sine|hash]
+//                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--csv] [--ndjson]
+//                   [--no-hipfft]
+#include <hipfft/hipfft.h>
+
+#include <cmath>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#define THUNDERFFT_ASYNC
+#include <thunderfft/thunderfft.cuh>
+
+#include "stat.hpp"
+
+namespace {
+
+// Same counter hash as fft_amd/synth.py: uniform(-1, 1) from (counter, seed).
+inline float hash_uniform(unsigned long long counter, unsigned long long seed) {
+  unsigned x = (unsigned)((counter * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull) >> 32);
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return (float)(x >> 8) * (2.0f / (1 << 24)) - 1.0f;
+}
+
+struct Args {
+  std::vector<int> ns = {256, 512, 1024, 2048, 4096, 8192, 16384};
+  long long points = 1ll << 28;
+  int runs = 10;
+  std::string input = "hash";
+  std::string dtype = "fp32";
+  int inplace = 1;
+  int mode = 0;
+  int grid = 0;
+  bool csv = false, ndjson = false, hipfft = true;
+};
+
+float time_ms(hipStream_t s, int warm, int runs, const std::function<void()>& fn) {
+  hipEvent_t a, b;
+  CHECK_HIP(hipEventCreate(&a));
+  CHECK_HIP(hipEventCreate(&b));
+  for (int i = 0; i < warm; ++i) fn();
+  CHECK_HIP(hipStreamSynchronize(s));
+  CHECK_HIP(hipEventRecord(a, s));
+  for (int i = 0; i < runs; ++i) fn();
+  CHECK_HIP(hipEventRecord(b, s));
+  CHECK_HIP(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK_HIP(hipEventElapsedTime(&ms, a, b));
+  CHECK_HIP(hipEventDestroy(a));
+  CHECK_HIP(hipEventDestroy(b));
+  return ms / runs;
+}
+
+// Reference check_max_abs_err (util/helper.h:94-120): largest |ref - test|, inf on any non-finite.
+double max_abs_err(const float2* ref, const float2* test, size_t n) {
+  double m = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double dx = (double)ref[i].x - test[i].x, dy = (double)ref[i].y - test[i].y;
+    const double e = std::sqrt(dx * dx + dy * dy);
+    if (!std::isfinite(test[i].x) || !std::isfinite(test[i].y) || !std::isfinite(e)) return INFINITY;
+    if (e > m) m = e;
+  }
+  return m;
+}
+
+void push_row(const std::string& type, int n, const std::string& radix, long long batch, double err, double ms,
+              double bytes_per_point) {
+  const double flops = 5.0 * n * std::log2((double)n) * batch;
+  const double bytes = bytes_per_point * (double)n * batch;
+  stat::push({type, (unsigned)n, radix, batch, err, ms, flops / ms * 1e-6, bytes / ms * 1e-6,
+              bytes / ms * 1e-6 / 8000.0});
+}
+
+template <typename T>
+void to_storage(const std::vector<float2>& h, std::vector<vec2_t<T>>& out) {
+  out.resize(h.size());
+  for (size_t i = 0; i < h.size(); ++i) {
+    if constexpr (std::is_same_v<T, float>) out[i] = h[i];
+    else if constexpr (std::is_same_v<T, __half>) out[i] = __floats2half2_rn(h[i].x, h[i].y);
+    else out[i] = __float22bfloat162_rn(h[i]);
+  }
+}
+template <typename T>
+float2 from_storage(vec2_t<T> v) {
+  if constexpr (std::is_same_v<T, float>) return v;
+  else if constexpr (std::is_same_v<T, __half>) return __half22float2(v);
+  else return __bfloat1622float2(v);
+}
+
+template <typename T>
+void run_one(const Args& a, int n) {
+  const long long batch = a.points / n;
+  const size_t total = (size_t)n * batch;
+  // validation runs on a bounded prefix so the host-side check stays short
+  const long long vbatch = std::min<long long>(batch, (1ll << 22) / n + 3);
+  const size_t vtotal = (size_t)n * vbatch;
+  const bool scaled = !std::is_same_v<T, float>;
+
+  std::vector<float2> h(vtotal);
+  for (size_t i = 0; i < vtotal; ++i) {
+    if (a.input == "sine") {  // reference input, sample/bench/main.cu:35-41
+      h[i] = make_float2(sinf(2 * (float)M_PI * (float)(i % n) / n) / sqrtf((float)n), 0.0f);
+    } else {
+      const float sc = scaled ? 1.0f / sqrtf((float)n) : 1.0f;
+      h[i] = make_float2(hash_uniform(2 * i + 1, 0) * sc, hash_uniform(2 * i + 2, 0) * sc);
+    }
+  }
+  std::vector<vec2_t<T>> hs;
+  to_storage<T>(h, hs);
+  for (size_t i = 0; i < vtotal; ++i) h[i] = from_storage<T>(hs[i]);  // what the device really holds
+
+  hipStream_t s;
+  CHECK_HIP(hipStreamCreate(&s));
+  vec2_t<T>*d_val = nullptr, *d_val_out = nullptr, *d_perf = nullptr, *d_perf_out = nullptr;
+  CHECK_HIP(hipMalloc(&d_val, sizeof(vec2_t<T>) * vtotal));
+  CHECK_HIP(hipMalloc(&d_val_out, sizeof(vec2_t<T>) * vtotal));
+  CHECK_HIP(hipMalloc(&d_perf, sizeof(vec2_t<T>) * total));
+  if (!a.inplace) CHECK_HIP(hipMalloc(&d_perf_out, sizeof(vec2_t<T>) * total));
+  CHECK_HIP(hipMemcpy(d_val, hs.data(), sizeof(vec2_t<T>) * vtotal, hipMemcpyHostToDevice));
+  // timing buffer: the validation pattern repeated (values do not matter for timing, but keep them finite)
+  for (size_t off = 0; off < total; off += vtotal) {
+    const size_t cnt = std::min(vtotal, total - off);
+    CHECK_HIP(hipMemcpy(d_perf + off, hs.data(), sizeof(vec2_t<T>) * cnt, hipMemcpyHostToDevice));
+  }
+
+  // ---- comparator: hipFFT fp32 on the same (storage-rounded) input
+  std::vector<float2> ref(vtotal);
+  double hipfft_ms = -1;
+  if (a.hipfft) {
+    float2 *d_f = nullptr, *d_fo = nullptr;
+    CHECK_HIP(hipMalloc(&d_f, sizeof(float2) * vtotal));
+    CHECK_HIP(hipMalloc(&d_fo, sizeof(float2) * vtotal));
+    CHECK_HIP(hipMemcpy(d_f, h.data(), sizeof(float2) * vtotal, hipMemcpyHostToDevice));
+    hipfftHandle plan;
+    if (hipfftPlan1d(&plan, n, HIPFFT_C2C, (int)vbatch) != HIPFFT_SUCCESS) { std::fprintf(stderr, "hipfftPlan1d failed\n"); std::exit(1); }
+    hipfftSetStream(plan, s);
+    hipfftExecC2C(plan, (hipfftComplex*)d_f, (hipfftComplex*)d_fo, HIPFFT_FORWARD);
+    CHECK_HIP(hipStreamSynchronize(s));
+    CHECK_HIP(hipMemcpy(ref.data(), d_fo, sizeof(float2) * vtotal, hipMemcpyDeviceToHost));
+    hipfftDestroy(plan);
+    CHECK_HIP(hipFree(d_f));
+    CHECK_HIP(hipFree(d_fo));
+    if (std::is_same_v<T, float>) {  // full-size hipFFT timing, in place like ours
+      hipfftHandle big;
+      if (hipfftPlan1d(&big, n, HIPFFT_C2C, (int)batch) == HIPFFT_SUCCESS) {
+        hipfftSetStream(big, s);
+        float2* buf = (float2*)d_perf;
+        float2* dst = a.inplace ? buf : (float2*)d_perf_out;
+        hipfft_ms = time_ms(s, 1, a.runs, [&] { hipfftExecC2C(big, (hipfftComplex*)buf, (hipfftComplex*)dst, HIPFFT_FORWARD); });
+        hipfftDestroy(big);
+        for (size_t off = 0; off < total; off += vtotal) {
+          const size_t cnt = std::min(vtotal, total - off);
+          CHECK_HIP(hipMemcpy(d_perf + off, hs.data(), sizeof(vec2_t<T>) * cnt, hipMemcpyHostToDevice));
+        }
+      }
+    }
+  }
+
+  // ---- ThunderFFT: validate, then time
+  thunderfft::ThunderFFTInitialize<T>(n);
+  const tfft_plan_info info = thunderfft::plan_info<T>(n);
+  std::ostringstream radix;
+  radix << info.radix[0] << "x" << info.radix[1];
+  if (info.radix[2] > 1) radix << "x" << info.radix[2];
+
+  tfft_set_option("mode", 0);
+  thunderfft::check(tfft_exec_c2c(thunderfft::dtype_code<T>(), n, 1, d_val, d_val_out, vbatch, s), "validate");
+  CHECK_HIP(hipStreamSynchronize(s));
+  std::vector<vec2_t<T>> got(vtotal);
+  CHECK_HIP(hipMemcpy(got.data(), d_val_out, sizeof(vec2_t<T>) * vtotal, hipMemcpyDeviceToHost));
+  double err = NAN;
+  if (a.hipfft) {
+    std::vector<float2> gf(vtotal);
+    for (size_t i = 0; i < vtotal; ++i) gf[i] = from_storage<T>(got[i]);
+    err = max_abs_err(ref.data(), gf.data(), vtotal);
+  }
+
+  tfft_set_option("mode", a.mode);
+  tfft_set_option("grid_blocks_per_cu", a.grid);
+  vec2_t<T>* dst = a.inplace ? d_perf : d_perf_out;
+  const float ms = time_ms(s, 1, a.runs, [&] {
+    thunderfft::check(tfft_exec_c2c(thunderfft::dtype_code<T>(), n, 1, d_perf, dst, batch, s), "bench");
+  });
+  tfft_set_option("mode", 0);
+
+  const double bpp = 2.0 * sizeof(vec2_t<T>);
+  push_row(std::string("thunderfft(") + a.dtype + (a.mode ? ",mode" + std::to_string(a.mode) : "") + ")", n, radix.str(),
+           batch, err, ms, bpp);
+  if (hipfft_ms > 0) push_row("hipfft(fp32)", n, "-", batch, 0.0, hipfft_ms, 16.0);
+
+  CHECK_HIP(hipFree(d_val));
+  CHECK_HIP(hipFree(d_val_out));
+  CHECK_HIP(hipFree(d_perf));
+  if (d_perf_out) CHECK_HIP(hipFree(d_perf_out));
+  CHECK_HIP(hipStreamDestroy(s));
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Args a;
+  for (int i = 1; i < argc; ++i) {
+    const std::string k = argv[i];
+    auto val = [&]() -> std::string { return (i + 1 < argc) ? argv[++i] : ""; };
+    if (k == "--n") {
+      a.ns.clear();
+      std::stringstream ss(val());
+      std::string tok;
+      while (std::getline(ss, tok, ',')) a.ns.push_back(std::stoi(tok));
+    } else if (k == "--points") a.points = std::stoll(val());
+    else if (k == "--runs") a.runs = std::stoi(val());
+    else if (k == "--input") a.input = val();
+    else if (k == "--dtype") a.dtype = val();
+    else if (k == "--inplace") a.inplace = std::stoi(val());
+    else if (k == "--mode") a.mode = std::stoi(val());
+    else if (k == "--grid") a.grid = std::stoi(val());
+    else if (k == "--csv") a.csv = true;
+    else if (k == "--ndjson") a.ndjson = true;
+    else if (k == "--no-hipfft") a.hipfft = false;
+    else { std::fprintf(stderr, "unknown argument %s\n", k.c_str()); return 2; }
+  }
+  CHECK_HIP(hipSetDevice(0));
+  try {
+    for (int n : a.ns) {
+      if (a.dtype == "fp32") run_one<float>(a, n);
+      else if (a.dtype == "fp16") run_one<__half>(a, n);
+      else if (a.dtype == "bf16") run_one<__hip_bfloat16>(a, n);
+      else { std::fprintf(stderr, "unknown dtype %s\n", a.dtype.c_str()); return 2; }
+    }
+    thunderfft::ThunderFFTFinalize<float>();
+    thunderfft::ThunderFFTFinalize<__half>();
+    thunderfft::ThunderFFTFinalize<__hip_bfloat16>();
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  stat::set_title("ThunderFFT (MI355X) benchmark, e2e = mean of " + std::to_string(a.runs) + " launches");
+  if (a.csv) stat::print_csv();
+  else if (a.ndjson) stat::print_ndjson();
+  else stat::print_table();
+  return 0;
+}

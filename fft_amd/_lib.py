@@ -1,0 +1,62 @@
+"""ctypes binding of libthunderfft_hip.so (C ABI declared in include/thunderfft_c.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libthunderfft_hip.so")
+
+# Every symbol include/thunderfft_c.h declares; tests check the list against the header.
+SYMBOLS = (
+    "tfft_initialize",
+    "tfft_finalize",
+    "tfft_exec_c2c",
+    "tfft_is_supported",
+    "tfft_get_plan_info",
+    "tfft_set_option",
+    "tfft_last_error",
+)
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int),
+        ("threads_per_block", ctypes.c_int),
+        ("transforms_per_block", ctypes.c_int),
+        ("points_per_thread", ctypes.c_int),
+        ("radix", ctypes.c_int * 3),
+        ("lds_bytes", ctypes.c_int),
+        ("blocks_per_cu", ctypes.c_int),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library. There is no fallback: a missing or unloadable library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); "
+            "fft_amd has no CPU or eager fallback")
+    # torch bundles its own libamdhip64.so.7; importing it first makes this library resolve
+    # the same HIP runtime, so device pointers and streams are shared with torch.
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH)
+    i, ll, vp, cp = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_char_p
+    lib.tfft_initialize.argtypes = [i, i]
+    lib.tfft_finalize.argtypes = [i]
+    lib.tfft_exec_c2c.argtypes = [i, i, i, vp, vp, ll, vp]
+    lib.tfft_is_supported.argtypes = [i, i, i]
+    lib.tfft_get_plan_info.argtypes = [i, i, ctypes.POINTER(PlanInfo)]
+    lib.tfft_set_option.argtypes = [cp, ll]
+    lib.tfft_last_error.argtypes = []
+    lib.tfft_last_error.restype = cp
+    for name in SYMBOLS:
+        if name != "tfft_last_error":
+            getattr(lib, name).restype = i
+    _lib = lib
+    return lib

@@ -1,0 +1,82 @@
+/* C ABI of libthunderfft_hip.so: batched 1D complex-to-complex FFT on MI355X (gfx950).
+ *
+ * The reference library is header-only CUDA C++ (thunderfft/include/thunderfft/thunderfft.cuh);
+ * it has no FFI layer, so the symbols below are what a binding for its three host entry
+ * points would call. The C++ templates in include/thunderfft/thunderfft.cuh forward to them.
+ *
+ * Data contract, identical to the reference (detail/kernel/global_kernel.cuh:37,49 and
+ * detail/thunderfft_impl_kernel.cuh:6-30): device pointers, `batch` contiguous transforms of
+ * n interleaved (re, im) points each, natural order in and out, unnormalised in both
+ * directions, `in == out` allowed.
+ *
+ * Every function returns 0 on success or a TFFT_ERR_* code; tfft_last_error() returns the
+ * message of the calling thread's last failure.
+ */
+#ifndef THUNDERFFT_C_H_
+#define THUNDERFFT_C_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Element type of the interleaved complex data in device memory. Arithmetic is fp32 for all. */
+enum { TFFT_F32 = 0, TFFT_F16 = 1, TFFT_BF16 = 2 };
+
+enum {
+  TFFT_OK = 0,
+  TFFT_ERR_UNSUPPORTED = 1,     /* n, dtype or direction has no kernel */
+  TFFT_ERR_NOT_INITIALIZED = 2, /* tfft_initialize(dtype, n) was not called on this device */
+  TFFT_ERR_INVALID = 3,         /* null pointer, negative batch, misaligned buffer */
+  TFFT_ERR_HIP = 4              /* a HIP runtime call failed; message holds hipGetErrorString */
+};
+
+/* Replaces thunderfft::ThunderFFTInitialize<T>(int N) (thunderfft.cuh:39-40; body
+ * detail/thunderfft_impl_twiddle.cuh:261-311): builds the twiddle table of length n in fp64
+ * on the host, rounds once to fp32 and uploads it to the current device. Tables are cached
+ * per (device, dtype, n); calling again with the same arguments is a no-op. Allocates. */
+int tfft_initialize(int dtype, int n);
+
+/* Replaces thunderfft::ThunderFFTFinalize<T>() (thunderfft.cuh:43-44; body
+ * thunderfft_impl_twiddle.cuh:342-349): frees every table of `dtype` on every device. */
+int tfft_finalize(int dtype);
+
+/* Replaces thunderfft::ThunderFFT_global<T, N, forward>(d_input, d_output, batch, stream)
+ * (thunderfft.cuh:98-102; body detail/thunderfft_impl_kernel.cuh:6-30). n is a run-time
+ * argument here. The launch is asynchronous on `stream` (a hipStream_t, may be NULL); the
+ * reference's trailing cudaStreamSynchronize is left to the caller (the C++ wrapper does it).
+ * n is a power of two in 64 ... 16384: one LDS-resident kernel per launch. */
+int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
+                  void* stream);
+
+/* 1 if tfft_exec_c2c has a kernel for (dtype, n, forward), else 0. The reference expresses the
+ * same through missing template specialisations (no inverse for N = 512 and 2048,
+ * detail/kernel/shared_kernel_n2048_b1.cuh:121-145). */
+int tfft_is_supported(int dtype, int n, int forward);
+
+/* Launch geometry of the kernel behind (dtype, n): the counterpart of the reference's
+ * batch_per_block<N>, warp_per_block<N> and shared-memory size (detail/thunderfft_impl.cuh:14-32,
+ * detail/thunderfft_impl_kernel.cuh:18). */
+typedef struct tfft_plan_info {
+  int n;
+  int threads_per_block;
+  int transforms_per_block;
+  int points_per_thread;
+  int radix[3];
+  int lds_bytes;
+  int blocks_per_cu; /* occupancy query result on the current device, 0 if not initialised */
+} tfft_plan_info;
+int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
+
+/* Tuning and measurement switches (no reference counterpart).
+ *   "grid_blocks_per_cu" : persistent grid = value * CU count (0 = library default)
+ *   "mode"               : 0 = FFT, 1 = load/store only, 2 = no LDS exchange (1 and 2 give wrong
+ *                          results on purpose; they price the memory pattern and the butterflies)
+ *   "sync"               : 1 = synchronise the stream after every launch like the reference */
+int tfft_set_option(const char* key, long long value);
+
+const char* tfft_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THUNDERFFT_C_H_ */

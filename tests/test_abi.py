@@ -1,0 +1,89 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the
+header declares, and reports the plan table. No compute call is made (no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "thunderfft_c.h")
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tfft_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_match_binding():
+    from fft_amd import _lib
+
+    assert _declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    from fft_amd import _lib
+
+    lib = _lib.load()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_supported_table():
+    import fft_amd
+
+    for code in (fft_amd.TFFT_F32, fft_amd.TFFT_F16, fft_amd.TFFT_BF16):
+        for n in fft_amd.SUPPORTED_N:
+            assert fft_amd.is_supported(code, n, True)
+            assert fft_amd.is_supported(code, n, False)  # the reference lacks inverse 512 / 2048
+        for n in (0, 1, 32, 96, 1000, 32768):
+            assert not fft_amd.is_supported(code, n, True)
+    assert not fft_amd.is_supported(7, 1024, True)
+
+
+def test_plan_info_geometry():
+    import fft_amd
+
+    for n in fft_amd.SUPPORTED_N:
+        info = fft_amd.plan_info("fp32", n)
+        assert info["n"] == n
+        prod = 1
+        for r in info["radix"]:
+            prod *= r
+        assert prod == n
+        assert info["threads_per_block"] % 64 == 0
+        assert info["points_per_thread"] * info["threads_per_block"] == n * info["transforms_per_block"]
+        assert info["lds_bytes"] <= 160 * 1024
+
+
+def test_errors_are_reported():
+    import fft_amd
+
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        fft_amd.plan_info("fp32", 1000)
+    assert e.value.code == 1 and "1000" in str(e.value)
+    with pytest.raises(fft_amd.ThunderFFTError):
+        fft_amd.set_option("no_such_option", 1)
+
+
+def test_host_wrapper_rejects_cpu_tensors():
+    import torch
+
+    import fft_amd
+
+    x = torch.zeros(2, 64, dtype=torch.complex64)
+    with pytest.raises(fft_amd.ThunderFFTError):
+        fft_amd.ThunderFFT_global(x, x, 2, 64)
+
+
+def test_synth_is_deterministic_and_bounded():
+    import numpy as np
+
+    from fft_amd import synth
+
+    a = synth.uniform_complex(4, 256, seed=0)
+    b = synth.uniform_complex(4, 256, seed=0)
+    c = synth.uniform_complex(4, 256, seed=1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.all(np.abs(a.real) <= 1) and np.all(np.abs(a.imag) <= 1)
+    assert abs(a.real.mean()) < 0.1 and 0.5 < a.real.std() < 0.65

@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the fp64 CPU oracle.
+
+Tolerances come from the build's accuracy gate: relative L2 error vs the fp64 DFT of the
+stored inputs <= 1e-5 for fp32, <= 1e-2 for fp16 / bf16 storage (the output rounding of a
+16-bit format alone is ~3e-4 / ~2e-3). The reference's own fp32 kernels multiply in TF32
+(thunderfft/include/thunderfft/detail/kernel/unit_kernel_fp32.cuh:123) and are not the target.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+import fft_amd  # noqa: E402
+from fft_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft_golden.npz")
+ALL_N = fft_amd.SUPPORTED_N
+TOL = {"fp32": 1e-5, "fp16": 1e-2, "bf16": 1e-2}
+TORCH_DT = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+def to_device(x, kind):
+    """complex64 numpy [batch, n] -> device tensor [batch, n, 2] of the storage type."""
+    t = torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(x.shape + (2,)))
+    return t.to("cuda").to(TORCH_DT[kind]).contiguous()
+
+
+def to_host(t):
+    """device tensor [batch, n, 2] -> complex128 numpy [batch, n]."""
+    a = t.float().cpu().numpy().astype(np.float64)
+    return a[..., 0] + 1j * a[..., 1]
+
+
+def run(x, kind, forward=True, inplace=False):
+    n = x.shape[-1]
+    d_in = to_device(x, kind)
+    d_out = d_in if inplace else torch.full_like(d_in, float("nan"))
+    fft_amd.ThunderFFTInitialize(kind, n)
+    fft_amd.ThunderFFT_global(d_in, d_out, x.shape[0], n, forward)
+    torch.cuda.synchronize()
+    return to_host(d_out), to_host(to_device(x, kind))
+
+
+@pytest.mark.parametrize("n", ALL_N)
+@pytest.mark.parametrize("forward", (True, False))
+def test_fp32_vs_oracle(oracle_mod, n, forward):
+    batch = max(3, 3 * 4096 // n + 1)  # not a multiple of the per-workgroup chunk: exercises the tail
+    x = synth.uniform_complex(batch, n, seed=n + int(forward))
+    got, stored = run(x, "fp32", forward)
+    ref = oracle_mod.fft(stored, forward)
+    err = oracle_mod.rel_l2(got, ref)
+    assert err <= TOL["fp32"], f"n={n} forward={forward} rel_l2={err:.3e}"
+    assert err <= 2e-6, f"fp32 accuracy regressed: n={n} rel_l2={err:.3e}"
+
+
+@pytest.mark.parametrize("n", ALL_N)
+@pytest.mark.parametrize("kind", ("fp16", "bf16"))
+def test_half_storage_vs_oracle(oracle_mod, n, kind):
+    batch = 2 * 4096 // n + 3
+    # pre-scaled by 1/sqrt(N) like the reference's half-precision bench input (sample/bench/main.cu:36)
+    x = synth.uniform_complex(batch, n, seed=7 * n, scale=1.0 / np.sqrt(n))
+    for forward in (True, False):
+        got, stored = run(x, kind, forward)
+        ref = oracle_mod.fft(stored, forward)
+        err = oracle_mod.rel_l2(got, ref)
+        assert err <= TOL[kind], f"{kind} n={n} forward={forward} rel_l2={err:.3e}"
+
+
+@pytest.mark.parametrize("n", ALL_N)
+def test_golden_vectors(oracle_mod, n):
+    g = np.load(GOLDEN)
+    x = g[f"x_{n}"]
+    got, _ = run(x, "fp32", True)
+    assert oracle_mod.rel_l2(got, g[f"fwd_{n}"]) <= TOL["fp32"]
+    got, _ = run(x, "fp32", False)
+    assert oracle_mod.rel_l2(got, g[f"inv_{n}"]) <= TOL["fp32"]
+
+
+@pytest.mark.parametrize("n", (64, 256, 1024, 4096, 16384))
+def test_in_place_equals_out_of_place(n):
+    batch = 40000 // n + 5
+    x = synth.uniform_complex(batch, n, seed=11)
+    a, _ = run(x, "fp32", True, inplace=False)
+    b, _ = run(x, "fp32", True, inplace=True)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("batch", (1, 2, 15, 16, 17, 63, 64, 65, 257))
+def test_ragged_batches_small_n(oracle_mod, batch):
+    # N=64 packs 64 transforms into one workgroup chunk: every tail shape must be exact
+    for n in (64, 256):
+        x = synth.uniform_complex(batch, n, seed=batch)
+        got, stored = run(x, "fp32", True)
+        assert oracle_mod.rel_l2(got, oracle_mod.fft(stored)) <= TOL["fp32"]
+
+
+def test_tail_does_not_write_past_the_batch():
+    n, batch, extra = 128, 37, 64
+    x = synth.uniform_complex(batch + extra, n, seed=5)
+    d = to_device(x, "fp32")
+    out = torch.full_like(d, 123.0)
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    fft_amd.ThunderFFT_global(d, out, batch, n, True)
+    torch.cuda.synchronize()
+    assert torch.all(out[batch:] == 123.0)
+    assert not torch.any(out[:batch] == 123.0)
+
+
+def test_empty_batch_is_a_noop():
+    d = torch.zeros(4, 64, 2, device="cuda")
+    fft_amd.ThunderFFTInitialize("fp32", 64)
+    fft_amd.ThunderFFT_global(d, d, 0, 64, True)
+    torch.cuda.synchronize()
+
+
+def test_kat_bench_sine():
+    # reference bench input: X[1] = -i sqrt(N)/2, X[N-1] = +i sqrt(N)/2 (sample/bench/main.cu:35-41)
+    for n in (128, 1024, 4096):
+        got, _ = run(synth.bench_sine(4, n), "fp32", True)
+        want = np.zeros((4, n), dtype=np.complex128)
+        want[:, 1] = -0.5j * np.sqrt(n)
+        want[:, n - 1] = 0.5j * np.sqrt(n)
+        assert np.max(np.abs(got - want)) < 2e-5
+
+
+def test_kat_fft1d_tones():
+    # reference fft1d sample: N=64, tones at bins 1+b and 7 (sample/fft1d/main.cu:16-30)
+    n, batch = 64, 40
+    got, _ = run(synth.fft1d_tones(batch, n), "fp32", True)
+    want = np.zeros((batch, n), dtype=np.complex128)
+    for b in range(batch):
+        want[b, (1 + b) % n] += n * (0.5 + 0.1 * b)
+        want[b, 7] += 0.1 * n
+    assert np.max(np.abs(got - want)) < 1e-3
+
+
+def test_kat_convolution_identity():
+    # IFFT(FFT(x) . FFT(h/N)) = circular convolution (conv1d_fullfft_l4096_thunder.cu:354-356, 472-490)
+    n, k = 4096, 31
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(n).astype(np.float32)
+    h = np.zeros(n, dtype=np.float32)
+    h[:k] = rng.standard_normal(k)
+    X, _ = run(x.astype(np.complex64)[None], "fp32", True)
+    H, _ = run((h / n).astype(np.complex64)[None], "fp32", True)
+    y, _ = run((X * H).astype(np.complex64), "fp32", False)
+    direct = np.array([np.dot(h[:k].astype(np.float64), x[(i - np.arange(k)) % n].astype(np.float64)) for i in range(n)])
+    assert np.max(np.abs(y[0] - direct)) < 1e-4
+
+
+@pytest.mark.parametrize("n,batch", ((256, 1 << 18), (4096, 1 << 14), (16384, 1 << 12)))
+def test_full_size_properties(n, batch):
+    """Size-independent checks at bench-scale batches (2^26 points): inverse(forward(x)) = N x,
+    Parseval per transform, and a spot check of 8 scattered transforms against torch's fp64 FFT."""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    X = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x, X, batch, n, True)
+    y = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(X, y, batch, n, False)
+    torch.cuda.synchronize()
+    rt = (torch.linalg.vector_norm((y / n - x).double()) / torch.linalg.vector_norm(x.double())).item()
+    assert rt < 2e-6, rt
+    ex = (x.double() ** 2).sum(dim=(1, 2))
+    eX = (X.double() ** 2).sum(dim=(1, 2)) / n
+    assert torch.max(torch.abs(eX / ex - 1)).item() < 1e-5
+    idx = torch.tensor([0, 1, batch // 3, batch // 2, batch - 2, batch - 1, 12345 % batch, 777 % batch], device="cuda")
+    ref = torch.fft.fft(torch.view_as_complex(x[idx].double().contiguous()), dim=-1)
+    got = torch.view_as_complex(X[idx].double().contiguous())
+    err = (torch.linalg.vector_norm(got - ref) / torch.linalg.vector_norm(ref)).item()
+    assert err < 1e-5, err
+
+
+def test_linearity():
+    n, batch = 2048, 33
+    a = synth.uniform_complex(batch, n, seed=1)
+    b = synth.uniform_complex(batch, n, seed=2)
+    A, _ = run(a, "fp32")
+    B, _ = run(b, "fp32")
+    C, _ = run((0.5 * a - 0.25j * b).astype(np.complex64), "fp32")
+    ref = 0.5 * A - 0.25j * B
+    assert np.linalg.norm(C - ref) / np.linalg.norm(ref) < 2e-6
+
+
+def test_exec_without_initialize_fails_loudly():
+    fft_amd.ThunderFFTFinalize("bf16")
+    d = torch.zeros(1, 64, 2, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        fft_amd.ThunderFFT_global(d, d, 1, 64, True)
+    assert e.value.code == 2
+
+
+def test_native_library_is_the_path():
+    # the product path must be the in-tree HIP library: it is mapped into this process
+    maps = open("/proc/self/maps").read()
+    assert "libthunderfft_hip.so" in maps

@@ -1,0 +1,179 @@
+"""LDS bank-conflict model for the in-LDS exchange stages of the batched FFT kernels.
+
+Mirrors the index arithmetic of fft_amd/csrc/fft_kernels.hip (first / middle / last pass
+butterfly -> logical exchange index -> padded physical index) and prices every
+ds_write_b64 / ds_read_b64 wave-instruction with the gfx950 banking rules:
+
+  ds_write_b64 : 4 groups of 16 consecutive lanes, bank = (byte/4) % 32
+  ds_read_b64  : 2 groups of 32 consecutive lanes, bank = (byte/4) % 64
+
+A group costs max-over-banks(number of distinct 8-byte words on that bank) LDS cycles.
+The script searches the one-level padding  phys(i) = i + (i >> PS) * PW  per exchange and
+prints the cheapest conflict-free (or least-conflicting) choice with the smallest LDS size.
+
+Usage: python tools/lds_conflicts.py            # table for every shipped configuration
+"""
+import itertools
+import sys
+
+
+def swz(tid):
+    """Virtual thread id that puts lanes l and l+32 of a wave on adjacent butterflies."""
+    return (tid & ~63) | ((tid & 31) << 1) | ((tid >> 5) & 1)
+
+
+def group_cost(addrs, nbanks):
+    """addrs: element (8-byte) indices of the lanes of one lane group."""
+    per_bank = {}
+    for a in addrs:
+        dw = 2 * a  # dword address of the low half; an 8-byte word covers banks dw, dw+1
+        per_bank.setdefault(dw % nbanks, set()).add(a)
+    return max(len(s) for s in per_bank.values())
+
+
+def instr_cost(addrs64, kind):
+    if kind == "w":
+        groups = [addrs64[g * 16:(g + 1) * 16] for g in range(4)]
+        return sum(group_cost(g, 32) for g in groups), 4
+    groups = [addrs64[g * 32:(g + 1) * 32] for g in range(2)]
+    return sum(group_cost(g, 64) for g in groups), 2
+
+
+class Cfg:
+    def __init__(self, N, E, R, WG):
+        self.N, self.E, self.R, self.WG = N, E, R, WG
+        self.T = N // E
+        self.TPB = max(1, WG // self.T)
+        assert self.T * self.TPB == WG, (N, E, WG)
+        self.P = len(R)
+
+    # butterfly ids handled by thread `tid` in a pass with NB butterflies per thread
+    def bfly_ids(self, tid, NB, paired):
+        if NB == 1:
+            return [swz(tid) if paired else tid]
+        if paired:
+            out = []
+            for pi in range(NB // 2):
+                g = 2 * (tid + self.WG * pi)
+                out += [g, g + 1]
+            return out
+        return [tid + self.WG * b for b in range(NB)]
+
+    # ---- exchange after the first pass: writer = first pass, reader = next pass
+    def ex1_write(self, tid):
+        N, R1 = self.N, self.R[0]
+        C1 = N // R1
+        out = []
+        for g in self.bfly_ids(tid, self.E // R1, True):
+            tr, c = divmod(g, C1)
+            out.append([tr * N + k1 * C1 + c for k1 in range(R1)])
+        return out  # list over butterflies of list over k1
+
+    def ex1_read(self, tid):
+        N, R1, R2 = self.N, self.R[0], self.R[1]
+        C1 = N // R1
+        if self.P == 2:
+            # last pass: butterfly q = k1, elements n2 (stride 1)
+            out = []
+            for g in self.bfly_ids(tid, self.E // R2, True):
+                tr, k1 = divmod(g, R1)
+                out.append([tr * N + k1 * C1 + n2 for n2 in range(R2)])
+            return out
+        R3 = self.R[2]
+        C2 = N // R2
+        out = []
+        for g in self.bfly_ids(tid, self.E // R2, False):
+            tr, q = divmod(g, C2)
+            k1, n3 = divmod(q, R3)
+            out.append([tr * N + k1 * C1 + n2 * R3 + n3 for n2 in range(R2)])
+        return out
+
+    # ---- exchange after the middle pass (3-pass plans)
+    def ex2_write(self, tid):
+        N, R1, R2, R3 = self.N, *self.R
+        C2 = N // R2
+        out = []
+        for g in self.bfly_ids(tid, self.E // R2, False):
+            tr, q = divmod(g, C2)
+            k1, n3 = divmod(q, R3)
+            out.append([tr * N + k2 * (R1 * R3) + k1 * R3 + n3 for k2 in range(R2)])
+        return out
+
+    def ex2_read(self, tid):
+        N, R1, R2, R3 = self.N, *self.R
+        C3 = N // R3
+        out = []
+        for g in self.bfly_ids(tid, self.E // R3, True):
+            tr, q3 = divmod(g, C3)
+            k2, k1 = divmod(q3, R1)
+            out.append([tr * N + k2 * (R1 * R3) + k1 * R3 + n3 for n3 in range(R3)])
+        return out
+
+
+def price(cfg, fn, kind, pad):
+    """Sum the cost of every wave-instruction of one access phase for one workgroup."""
+    per_thread = [fn(t) for t in range(cfg.WG)]
+    nb = len(per_thread[0])
+    ne = len(per_thread[0][0])
+    tot = base = 0
+    for w in range(cfg.WG // 64):
+        for b in range(nb):
+            for e in range(ne):
+                addrs = [pad(per_thread[w * 64 + l][b][e]) for l in range(64)]
+                c, b0 = instr_cost(addrs, kind)
+                tot += c
+                base += b0
+    return tot, base
+
+
+def make_pad(ps, pw):
+    if pw == 0:
+        return lambda i: i
+    return lambda i: i + (i >> ps) * pw
+
+
+def search(cfg, wfn, rfn, label):
+    best = None
+    total = cfg.N * cfg.TPB
+    cands = [(0, 0)] + [(ps, pw) for ps in range(2, 12) for pw in (1, 2, 4, 8, 16)]
+    for ps, pw in cands:
+        pad = make_pad(ps, pw)
+        size = pad(total - 1) + 1
+        if size * 8 > 160 * 1024:
+            continue
+        wc, wb = price(cfg, wfn, "w", pad)
+        rc, rb = price(cfg, rfn, "r", pad)
+        # write conflicts only cost once the LDS-array cycles exceed the ~6-cycle issue cost
+        score = (rc / rb) + 0.6 * max(wc / wb, 1.5) + 1e-3 * size / total
+        rec = (score, ps, pw, size, wc / wb, rc / rb)
+        if best is None or rec < best:
+            best = rec
+    _, ps, pw, size, wf, rf = best
+    print(f"  {label}: PS={ps} PW={pw} lds_elems={size} ({size * 8} B)  write x{wf:.2f}  read x{rf:.2f}")
+    return ps, pw, size
+
+
+CONFIGS = [
+    (64, 16, (16, 4), 256),
+    (128, 16, (16, 8), 256),
+    (256, 16, (16, 16), 256),
+    (512, 16, (16, 8, 4), 256),
+    (1024, 16, (16, 16, 4), 256),
+    (2048, 16, (16, 16, 8), 256),
+    (4096, 16, (16, 16, 16), 256),
+    (8192, 32, (32, 16, 16), 256),
+    (16384, 32, (32, 32, 16), 512),
+]
+
+
+def main():
+    for N, E, R, WG in CONFIGS:
+        cfg = Cfg(N, E, R, WG)
+        print(f"N={N} E={E} R={R} WG={WG} TPB={cfg.TPB}")
+        search(cfg, cfg.ex1_write, cfg.ex1_read, "exchange 1")
+        if cfg.P == 3:
+            search(cfg, cfg.ex2_write, cfg.ex2_read, "exchange 2")
+
+
+if __name__ == "__main__":
+    main()
