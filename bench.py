@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched 1D C2C FFT, N=4096 fp32, 2^28 points per GPU, on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one pass of the hot path (tfft_exec_c2c through the C ABI) over the whole batch,
+in place on a device-resident buffer, the way the reference times its own kernel
+(thunderfft/sample/bench/util/helper.h:138-141, baseline/thunderfft_bench.h:124-131). For N > 1
+the driver starts one process per GPU (torch.distributed.run); the batch dimension shards
+trivially, every rank transforms its own 2^28 points (weak scaling) and no collective touches
+the data path. Rank 0 prints ONE JSON line:
+
+  value        whole-job GFLOP/s with the 5 N log2 N convention, inputs resident in HBM
+  roofline     algorithmic HBM bytes (16 B per point: one read + one write) per launch divided
+               by the mean launch duration measured with events on the launch stream, against
+               8 TB/s; `traffic` is the PMC-measured HBM bytes per launch recorded under
+               profiles/ for this same kernel (null if no such record matches)
+  cpu_baseline the CPU FFT (scipy/pocketfft on complex64, all host cores of the box's share)
+               timed on a bounded sample of the same workload; a reported baseline, not a target
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_FFT = 4096
+BATCH = 65536  # 2^28 points: 2 GiB of fp32 complex per GPU
+HBM_PEAK_GBPS = 8000.0
+BYTES_PER_POINT = 16  # fp32 complex read once + written once
+
+
+def cpu_baseline(n, seconds_budget=12.0):
+    """CPU FFT of the same shape on a bounded sample, best of 3 (BASELINE.md protocol)."""
+    import numpy as np
+    import scipy.fft
+
+    import oracle  # noqa: F401  (the CPU side lives with the oracle; this leg is its only bench user)
+    from fft_amd import synth
+
+    cores = max(1, min(16, os.cpu_count() or 1))
+    batch = 4096  # 2^24 points = 128 MiB of complex64
+    x = synth.uniform_complex(batch, n, seed=0)
+    flops = 5.0 * n * math.log2(n) * batch
+
+    def best(fn, reps=3):
+        fn()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            t.append(time.perf_counter() - t0)
+        return min(t)
+
+    t_multi = best(lambda: scipy.fft.fft(x, axis=-1, workers=cores))
+    t_single = best(lambda: np.fft.fft(x, axis=-1))
+    return {
+        "value": round(flops / t_multi * 1e-9, 2),
+        "unit": "GFLOP/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"scipy.fft.fft complex64 N={n} batch={batch} (2^24 points), workers={cores}, best of 3",
+        "single_thread_numpy_gflops": round(flops / t_single * 1e-9, 2),
+    }
+
+
+def recorded_traffic(kernel_tag):
+    """HBM bytes per launch from the committed PMC summary, if it describes this kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    entry = rec.get(kernel_tag)
+    return entry.get("hbm_bytes_per_launch") if entry else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_FFT)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--out-of-place", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import fft_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the FFT path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, batch = args.n, args.batch
+    # synthetic input, uniform(-1, 1), generated on the device (values do not affect timing)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand(batch, n, 2, device=dev, generator=g) * 2 - 1
+    # An unnormalised forward FFT grows random data by sqrt(N) per pass. In place, start low enough
+    # (an exact power of two, mantissas untouched) that up to RESCALE_EVERY passes stay finite.
+    RESCALE_EVERY = 32
+    if not args.out_of_place:
+        x.mul_(float(n) ** (-min(args.steps + args.warmup, RESCALE_EVERY) / 4.0))
+    y = torch.empty_like(x) if args.out_of_place else x
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        fft_amd.ThunderFFT_global(x, y, batch, n, True, stream)
+
+    done = 0
+
+    def keep_finite():
+        # only reached on runs longer than RESCALE_EVERY passes; outside the event-timed launches
+        nonlocal done
+        done += 1
+        if not args.out_of_place and done % RESCALE_EVERY == 0:
+            x.mul_(float(n) ** (-RESCALE_EVERY / 2.0))
+
+    for _ in range(args.warmup):
+        step()
+        keep_finite()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record(stream)
+        step()
+        ends[i].record(stream)
+        keep_finite()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+
+    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+    if dist:
+        t = torch.tensor([wall, kernel_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = t[0].item(), t[1].item()
+
+    ms_per_step = wall / args.steps * 1e3
+    flops_per_step = 5.0 * n * math.log2(n) * batch * world
+    bytes_per_launch = BYTES_PER_POINT * n * batch
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) * 1e-9
+
+    if rank == 0:
+        info = fft_amd.plan_info("fp32", n)
+        line = {
+            "metric": "batched 1D C2C FFT GFLOP/s (5NlogN) + % HBM roofline, N=4096 fp32",
+            "value": round(flops_per_step / (ms_per_step * 1e-3) * 1e-9, 1),
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batched 1D C2C FFT N={n} batch={batch} per GPU fp32, "
+                            f"{'out of place' if args.out_of_place else 'in place'}, forward",
+                "points_per_gpu": n * batch,
+                "radix": "x".join(str(r) for r in info["radix"]),
+                "parallelism": f"batch-sharded x{world}, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": recorded_traffic(f"fft_lds_kernel_f32_n{n}_b{batch}"),
+                "kernel": "fft_lds_kernel<Plan4096, StoreF32, forward>" if n == 4096 else f"fft_lds_kernel n={n}",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(line), flush=True)
+
+    fft_amd.ThunderFFTFinalize("fp32")
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

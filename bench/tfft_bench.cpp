@@ -6,7 +6,7 @@
 // reports GFLOP/s (5 N log2 N), GB/s (one read + one write per point) and the fraction of 8 TB/s.
 //
 // Usage: tfft_bench [--n 256,4096] [--points 268435456] [--runs 10] [--input sine|hash]
-//                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--csv] [--ndjson]
+//                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--extra-lds BYTES] [--csv] [--ndjson]
 //                   [--no-hipfft]
 #include <hipfft/hipfft.h>
 
@@ -43,6 +43,7 @@ struct Args {
   int inplace = 1;
   int mode = 0;
   int grid = 0;
+  int extra_lds = 0;
   bool csv = false, ndjson = false, hipfft = true;
 };
 
@@ -189,11 +190,13 @@ void run_one(const Args& a, int n) {
 
   tfft_set_option("mode", a.mode);
   tfft_set_option("grid_blocks_per_cu", a.grid);
+  tfft_set_option("extra_lds", a.extra_lds);
   vec2_t<T>* dst = a.inplace ? d_perf : d_perf_out;
   const float ms = time_ms(s, 1, a.runs, [&] {
     thunderfft::check(tfft_exec_c2c(thunderfft::dtype_code<T>(), n, 1, d_perf, dst, batch, s), "bench");
   });
   tfft_set_option("mode", 0);
+  tfft_set_option("extra_lds", 0);
 
   const double bpp = 2.0 * sizeof(vec2_t<T>);
   push_row(std::string("thunderfft(") + a.dtype + (a.mode ? ",mode" + std::to_string(a.mode) : "") + ")", n, radix.str(),
@@ -226,6 +229,7 @@ int main(int argc, char** argv) {
     else if (k == "--inplace") a.inplace = std::stoi(val());
     else if (k == "--mode") a.mode = std::stoi(val());
     else if (k == "--grid") a.grid = std::stoi(val());
+    else if (k == "--extra-lds") a.extra_lds = std::stoi(val());
     else if (k == "--csv") a.csv = true;
     else if (k == "--ndjson") a.ndjson = true;
     else if (k == "--no-hipfft") a.hipfft = false;

@@ -25,15 +25,19 @@ using Plan16384 = Plan<16384, 32, 32, 32, 16, 512, 9, 16, 5, 1>;
 struct KernelEntry {
   const void* fn;  // __global__ function address (for the occupancy query)
   void (*launch)(const void* in, void* out, const float2* tw, long long batch, long long nchunks,
-                 unsigned grid, hipStream_t stream);
+                 unsigned grid, unsigned extra_lds, hipStream_t stream);
   int n, threads, tpb, e, radix[3], lds_bytes;
 };
 
 template <class P, class IO, bool FWD, int MODE>
 void launch_plan(const void* in, void* out, const float2* tw, long long batch, long long nchunks,
-                 unsigned grid, hipStream_t stream) {
+                 unsigned grid, unsigned extra_lds, hipStream_t stream) {
   using raw = typename IO::raw;
-  fft_lds_kernel<P, IO, FWD, MODE><<<dim3(grid), dim3(P::WG), 0, stream>>>(
+  // extra_lds: unused dynamic LDS that only lowers the number of co-resident workgroups per CU
+  if (extra_lds)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_lds_kernel<P, IO, FWD, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)extra_lds);
+  fft_lds_kernel<P, IO, FWD, MODE><<<dim3(grid), dim3(P::WG), extra_lds, stream>>>(
       static_cast<const raw*>(in), static_cast<raw*>(out), tw, batch, nchunks);
 }
 

@@ -48,6 +48,7 @@ struct Options {
   long long grid_blocks_per_cu = 0;
   long long mode = 0;
   long long sync = 0;
+  long long extra_lds = 0;
 };
 
 std::mutex g_mu;
@@ -166,6 +167,7 @@ int tfft_set_option(const char* key, long long value) {
   if (!strcmp(key, "grid_blocks_per_cu")) g_opt.grid_blocks_per_cu = value;
   else if (!strcmp(key, "mode")) g_opt.mode = value;
   else if (!strcmp(key, "sync")) g_opt.sync = value;
+  else if (!strcmp(key, "extra_lds")) g_opt.extra_lds = value;
   else return fail(TFFT_ERR_INVALID, "tfft_set_option: unknown key '%s'", key);
   return TFFT_OK;
 }
@@ -200,13 +202,15 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
                 dtype_name(dtype), n, forward, opt.mode);
 
   const long long nchunks = (batch + e.tpb - 1) / e.tpb;
-  long long per_cu = opt.grid_blocks_per_cu > 0 ? opt.grid_blocks_per_cu
-                                                : (long long)plan.blocks_per_cu[forward ? 0 : 1];
-  if (per_cu < 1) per_cu = 1;
-  long long grid = per_cu * plan.cu_count;
+  // Default: one workgroup per chunk. The hardware dispatcher then hands out chunks in address
+  // order as workgroups retire, which streams HBM measurably better than a resident grid walking
+  // the batch with a stride; "grid_blocks_per_cu" selects the resident (persistent) form instead.
+  long long grid = nchunks;
+  if (opt.grid_blocks_per_cu > 0) grid = opt.grid_blocks_per_cu * plan.cu_count;
   if (grid > nchunks) grid = nchunks;
+  if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, s);
+  e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, (unsigned)opt.extra_lds, s);
   TFFT_HIP(hipGetLastError());
   if (opt.sync) TFFT_HIP(hipStreamSynchronize(s));
   return TFFT_OK;

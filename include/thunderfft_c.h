@@ -68,7 +68,9 @@ typedef struct tfft_plan_info {
 int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
 
 /* Tuning and measurement switches (no reference counterpart).
- *   "grid_blocks_per_cu" : persistent grid = value * CU count (0 = library default)
+ *   "grid_blocks_per_cu" : resident grid of value * CU count workgroups that walk the batch
+ *                          (0 = default: one workgroup per chunk of transforms)
+ *   "extra_lds"          : bytes of unused dynamic LDS per workgroup, to lower occupancy
  *   "mode"               : 0 = FFT, 1 = load/store only, 2 = no LDS exchange (1 and 2 give wrong
  *                          results on purpose; they price the memory pattern and the butterflies)
  *   "sync"               : 1 = synchronise the stream after every launch like the reference */
