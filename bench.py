@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" is one pass of the hot path (tfft_exec_c2c through the C ABI) over the whole batch,
-in place on a device-resident buffer, the way the reference times its own kernel
-(thunderfft/sample/bench/util/helper.h:138-141, baseline/thunderfft_bench.h:124-131). For N > 1
+from one device-resident buffer to another, the call shape of the reference's public entry point
+(thunderfft/sample/fft1d/main.cu:116; `--in-place` selects the reference bench's in-place form,
+thunderfft/sample/bench/baseline/thunderfft_bench.h:124-131). For N > 1
 the driver starts one process per GPU (torch.distributed.run); the batch dimension shards
 trivially, every rank transforms its own 2^28 points (weak scaling) and no collective touches
 the data path. Rank 0 prints ONE JSON line:
@@ -87,9 +88,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=N_FFT)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--out-of-place", action="store_true")
+    ap.add_argument("--in-place", action="store_true", help="transform the buffer in place (the reference bench protocol) instead of x -> y")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    args.out_of_place = not args.in_place
 
     import torch
 
