@@ -197,7 +197,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": recorded_traffic(f"fft_lds_kernel_f32_n{n}_b{batch}"),
-                "kernel": "fft_lds_kernel<Plan4096, StoreF32, forward>" if n == 4096 else f"fft_lds_kernel n={n}",
+                "kernel": f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },

@@ -34,6 +34,15 @@ inline float hash_uniform(unsigned long long counter, unsigned long long seed) {
   return (float)(x >> 8) * (2.0f / (1 << 24)) - 1.0f;
 }
 
+// Speed-of-light reference measured in the same process: a one-shot nontemporal float4 copy
+// (one 16-byte load and store per thread, 4 KiB per workgroup), the fastest streaming copy found
+// on MI355X. Boxes differ by several percent, so every table carries its own copy row.
+typedef float copy_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void reference_copy(const copy_f32x4* in, copy_f32x4* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
 struct Args {
   std::vector<int> ns = {256, 512, 1024, 2048, 4096, 8192, 16384};
   long long points = 1ll << 28;
@@ -202,6 +211,14 @@ void run_one(const Args& a, int n) {
   push_row(std::string("thunderfft(") + a.dtype + (a.mode ? ",mode" + std::to_string(a.mode) : "") + ")", n, radix.str(),
            batch, err, ms, bpp);
   if (hipfft_ms > 0) push_row("hipfft(fp32)", n, "-", batch, 0.0, hipfft_ms, 16.0);
+  {
+    const size_t bytes = sizeof(vec2_t<T>) * total;
+    copy_f32x4* cdst = reinterpret_cast<copy_f32x4*>(a.inplace ? d_perf : d_perf_out);
+    const float cms = time_ms(s, 1, a.runs, [&] {
+      reference_copy<<<(unsigned)(bytes / 4096), 256, 0, s>>>(reinterpret_cast<const copy_f32x4*>(d_perf), cdst);
+    });
+    push_row("copy16B(reference)", n, "-", batch, 0.0, cms, bpp);
+  }
 
   CHECK_HIP(hipFree(d_val));
   CHECK_HIP(hipFree(d_val_out));

@@ -26,6 +26,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "butterfly.hpp"
 
 namespace tfft {
@@ -134,14 +136,23 @@ struct StoreBF16 {
 // ---------------------------------------------------------------------------------------
 // Plan constants shared by host and device.
 // ---------------------------------------------------------------------------------------
-template <int N_, int E_, int R1_, int R2_, int R3_, int WG_, int PS1_, int PW1_, int PS2_, int PW2_, int MINW_ = 1, bool HOIST_ = false>
+enum : int { kFlagPrefetch = 1, kFlagSplit = 2, kFlagHoist = 4 };
+
+template <int N_, int E_, int R1_, int R2_, int R3_, int WG_, int PS1_, int PW1_, int PS2_, int PW2_, int MINW_ = 1,
+          int FLAGS_ = 0>
 struct Plan {
   static constexpr int N = N_, E = E_, R1 = R1_, R2 = R2_, R3 = R3_, WG = WG_;
   static constexpr int PS1 = PS1_, PW1 = PW1_, PS2 = PS2_, PW2 = PW2_;
   static constexpr int MINW = MINW_;  // waves per SIMD the register allocator must leave room for
-  // true: the twiddle powers are loop invariants the compiler may keep in VGPRs across chunks;
-  // false: they are recomputed from the base twiddle for every chunk (fewer live registers)
-  static constexpr bool HOIST = HOIST_;
+  // PREFETCH: a resident workgroup requests the rows of its next chunk before it computes the
+  //           current one (costs E/2 more live 16-byte registers); without it the kernel is a
+  //           plain load -> compute -> store body, meant for one workgroup per chunk.
+  // SPLIT   : the LDS exchanges move real and imaginary parts in two rounds through a buffer of
+  //           N floats instead of N float2: half the LDS, twice the barriers.
+  // HOIST   : twiddle powers are loop invariants the compiler may keep in VGPRs across chunks.
+  static constexpr bool PREFETCH = (FLAGS_ & kFlagPrefetch) != 0;
+  static constexpr bool SPLIT = (FLAGS_ & kFlagSplit) != 0;
+  static constexpr bool HOIST = (FLAGS_ & kFlagHoist) != 0;
   static constexpr int PASSES = (R3 > 1) ? 3 : 2;
   static constexpr int RL = (R3 > 1) ? R3 : R2;  // radix of the last pass
   static constexpr int T = N / E;                // threads per transform
@@ -155,6 +166,7 @@ struct Plan {
   static constexpr int LDS1 = pad1(TOTAL - 1) + 1;
   static constexpr int LDS2 = (PASSES == 3) ? pad2(TOTAL - 1) + 1 : 0;
   static constexpr int LDS_ELEMS = LDS1 > LDS2 ? LDS1 : LDS2;
+  static constexpr int LDS_BYTES = LDS_ELEMS * (SPLIT ? 4 : 8);
   static_assert(R1 * R2 * R3 == N, "radices must multiply to N");
   static_assert(T * TPB == WG && TPB >= 1, "workgroup must hold whole transforms");
   static_assert(E % R1 == 0 && E % R2 == 0 && E % RL == 0, "radix must divide points per thread");
@@ -174,20 +186,17 @@ __device__ __forceinline__ int pad_idx(int i) {
   return i + (i >> PS) * PW;
 }
 
-// Slots of base + e*S for e = 0..R-1. When the stride cannot carry into the padded bits in
-// a data dependent way the slots are pad(base) + e*const and become ds_* immediates.
-template <int PS, int PW, int S, int R>
-struct PadWalk {
-  static constexpr bool kWhole = (PW == 0) || (S % (1 << PS) == 0);
-  // base is always a multiple of R*S in the callers, so small strides stay inside one pad period
-  static constexpr bool kInside = (PW != 0) && (R * S <= (1 << PS));
-  static constexpr bool kAffine = kWhole || kInside;
-  static constexpr int kStep = (PW == 0) ? S : (kWhole ? S + (S >> PS) * PW : S);
-  __device__ static __forceinline__ int slot(int base_logical, int base_slot, int e) {
-    if constexpr (kAffine) return base_slot + e * kStep;
-    return pad_idx<PS, PW>(base_logical + e * S);
-  }
-};
+// Slot of logical index base + e*S (e = 0..R-1). Two cases are affine in e, so that the slots
+// become base register + immediate offset: strides that are whole pad periods, and runs that stay
+// inside one pad period (INSIDE: the caller guarantees base is a multiple of R*S).
+template <int PS, int PW, int S, int R, bool INSIDE>
+__device__ __forceinline__ int walk_slot(int base, int base_slot, int e) {
+  constexpr bool whole = (PW == 0) || (S % (1 << PS) == 0);
+  constexpr bool inside = INSIDE && (R * S <= (1 << PS));
+  if constexpr (whole) return base_slot + e * ((PW == 0) ? S : S + (S >> PS) * PW);
+  if constexpr (inside) return base_slot + e * S;
+  return pad_idx<PS, PW>(base + e * S);
+}
 
 enum : int { kModeFFT = 0, kModeCopy = 1, kModeNoLds = 2 };
 
@@ -201,14 +210,17 @@ __device__ __forceinline__ c32 fresh(c32 w) {
 
 template <class P, class IO, bool FWD, int MODE>
 __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename IO::raw* in, typename IO::raw* out,
-                                                         const float2* __restrict__ tw, long long batch,
-                                                         long long nchunks) {
+                                                                 const float2* __restrict__ tw, long long batch,
+                                                                 long long nchunks) {
   using raw = typename IO::raw;
   constexpr int N = P::N, E = P::E, R1 = P::R1, R2 = P::R2, R3 = P::R3, RL = P::RL, WG = P::WG;
   constexpr int C1 = P::C1, C2 = P::C2, CL = P::CL, NB1 = P::NB1, NB2 = P::NB2, NBL = P::NBL;
   constexpr int NRAW = P::NRAW, TPB = P::TPB;
+  constexpr bool SPLIT = P::SPLIT;
 
-  __shared__ float2 lds[P::LDS_ELEMS];
+  __shared__ __attribute__((aligned(16))) char lds_raw[P::LDS_BYTES];
+  float2* const lds2 = reinterpret_cast<float2*>(lds_raw);
+  float* const lds1 = reinterpret_cast<float*>(lds_raw);
 
   const int tid = threadIdx.x;
   const int hi = (tid >> 5) & 1;  // upper half of the wave
@@ -237,6 +249,26 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
     }
   }
 
+  // ---- the first chunk's rows are requested before anything else is set up: a workgroup's
+  // lifetime starts with this HBM round trip, and everything below (store offsets, twiddle
+  // bases, LDS slots) is computed while it is in flight.
+  const long long chunk_raw = (long long)P::TOTAL / 2;  // raw elements per chunk
+  auto issue_loads = [&](long long chunk, raw (&dst)[NRAW]) {
+    const raw* src = in + chunk * chunk_raw;
+    const long long tr0 = chunk * TPB;
+#pragma unroll
+    for (int g = 0; g < NG1; ++g) {
+      const bool ok = (TPB == 1) || (tr0 + ld_tr[g] < batch);
+      const raw* p = src + ld_base[g];
+#pragma unroll
+      for (int i = 0; i < LPG1; ++i) dst[g * LPG1 + i] = ok ? IO::load(p + i * (C1 / 2)) : IO::zero();
+    }
+  };
+  raw pre[NRAW];
+  long long chunk = blockIdx.x;
+  if (chunk >= nchunks) return;
+  issue_loads(chunk, pre);
+
   // ---- last pass: butterflies and raw stores, same shape with CL in place of C1
   constexpr int NGL = (NBL == 1) ? 1 : NBL / 2;
   constexpr int SPGL = NRAW / NGL;
@@ -260,11 +292,7 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
     }
   }
 
-  // ---- loop-invariant twiddle bases
-  c32 w1[NB1];
-#pragma unroll
-  for (int b = 0; b < NB1; ++b) w1[b] = tw[b1_c[b]];  // W_N^c
-  c32 w2[NB2];
+  // ---- middle pass butterflies (three-pass plans): butterfly (k1, n3) of transform tr
   int b2_tr[NB2], b2_k1[NB2], b2_n3[NB2];
   if constexpr (P::PASSES == 3) {
 #pragma unroll
@@ -274,33 +302,94 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
       const int q = g % C2;
       b2_k1[b] = q / R3;
       b2_n3[b] = q % R3;
-      w2[b] = tw[b2_n3[b] * R1];  // W_{R2 R3}^{n3}
     }
   }
 
-  const long long chunk_raw = (long long)P::TOTAL / 2;  // raw elements per chunk
+  // ---- twiddle bases, one per butterfly: W_N^c after the first pass, W_{R2 R3}^{n3} after the middle one
+  c32 w1[NB1], w2[NB2];
+#pragma unroll
+  for (int b = 0; b < NB1; ++b) w1[b] = tw[b1_c[b]];
+  if constexpr (P::PASSES == 3) {
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) w2[b] = tw[b2_n3[b] * R1];
+  }
 
-  auto issue_loads = [&](long long chunk, raw (&dst)[NRAW]) {
-    const raw* src = in + chunk * chunk_raw;
-    const long long tr0 = chunk * TPB;
+  // ---- LDS slots. Writer element (b, j) and reader element (b, j) of each exchange.
+  // exchange 1 holds Y1[tr][k1][c] at logical index tr*N + k1*C1 + c
+  auto ex1_wslot = [&](int b, int k1) {
+    const int base = b1_tr[b] * N + b1_c[b];
+    return walk_slot<P::PS1, P::PW1, C1, R1, false>(base, pad_idx<P::PS1, P::PW1>(base), k1);
+  };
+  auto ex1_rslot_mid = [&](int b, int n2) {  // middle pass: butterfly (k1, n3) reads n2 = 0..R2-1, stride R3
+    const int base = b2_tr[b] * N + b2_k1[b] * C1 + b2_n3[b];
+    return walk_slot<P::PS1, P::PW1, R3, R2, false>(base, pad_idx<P::PS1, P::PW1>(base), n2);
+  };
+  auto ex1_rslot_last = [&](int b, int n2) {  // two-pass plans: butterfly k1 reads n2 = 0..R2-1, stride 1
+    const int base = bl_tr[b] * N + bl_q[b] * C1;
+    return walk_slot<P::PS1, P::PW1, 1, R2, true>(base, pad_idx<P::PS1, P::PW1>(base), n2);
+  };
+  // exchange 2 holds Y2[tr][k2][k1][n3] at logical index tr*N + k2*(R1*R3) + k1*R3 + n3
+  auto ex2_wslot = [&](int b, int k2) {
+    const int base = b2_tr[b] * N + b2_k1[b] * R3 + b2_n3[b];
+    return walk_slot<P::PS2, P::PW2, R1 * R3, R2, false>(base, pad_idx<P::PS2, P::PW2>(base), k2);
+  };
+  auto ex2_rslot = [&](int b, int n3) {  // last pass: butterfly q = k1 + R1*k2 reads n3 = 0..R3-1
+    const int k1 = bl_q[b] % R1, k2 = bl_q[b] / R1;
+    const int base = bl_tr[b] * N + k2 * (R1 * R3) + k1 * R3;
+    return walk_slot<P::PS2, P::PW2, 1, R3, true>(base, pad_idx<P::PS2, P::PW2>(base), n3);
+  };
+
+  // One exchange: every thread writes its E values (writer radix RW: element e = b*RW + j) and
+  // reads back E values in the next pass's order (reader radix RR). `lead` inserts the barrier
+  // that protects a previous exchange's readers from this one's writes.
+  auto exchange = [&](c32 (&v)[E], auto wslot, auto rslot, auto rw_tag, auto rr_tag, bool lead) {
+    constexpr int RW = decltype(rw_tag)::value, RR = decltype(rr_tag)::value;
+    if (lead) __syncthreads();
+    if constexpr (!SPLIT) {
 #pragma unroll
-    for (int g = 0; g < NG1; ++g) {
-      const bool ok = (TPB == 1) || (tr0 + ld_tr[g] < batch);
-      const raw* p = src + ld_base[g];
+      for (int e = 0; e < E; ++e) lds2[wslot(e / RW, e % RW)] = v[e];
+      __syncthreads();
 #pragma unroll
-      for (int i = 0; i < LPG1; ++i) dst[g * LPG1 + i] = ok ? IO::load(p + i * (C1 / 2)) : IO::zero();
+      for (int e = 0; e < E; ++e) v[e] = lds2[rslot(e / RR, e % RR)];
+    } else {
+      float re[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) lds1[wslot(e / RW, e % RW)] = v[e].x;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) re[e] = lds1[rslot(e / RR, e % RR)];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) lds1[wslot(e / RW, e % RW)] = v[e].y;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = make_float2(re[e], lds1[rslot(e / RR, e % RR)]);
     }
   };
 
-  // Software pipeline: the rows of chunk i+1 are requested right after chunk i has been
-  // unpacked, so they land while chunk i is computed and stored. The first trip is written
-  // out ahead of the loop: both ways into the loop then carry "8 loads, then 8 stores" in
-  // flight and the wait for the prefetched rows is a counted vmcnt that leaves the stores
-  // of the previous chunk outstanding.
-  raw pre[NRAW];
-  auto process = [&](long long chunk) __attribute__((always_inline)) {
+  // radix-R butterflies on v[b*R .. b*R+R-1], then the inter-pass twiddles w[b]^j
+  auto butterflies = [&](c32 (&v)[E], auto r_tag, const c32* w) {
+    constexpr int R = decltype(r_tag)::value;
+#pragma unroll
+    for (int b = 0; b < E / R; ++b) {
+      c32 x[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) x[j] = v[b * R + j];
+      dft<R>(x);
+      if (w != nullptr) {
+        c32 pw[R];
+        twiddle_powers<R>(fresh<P::HOIST>(w[b]), pw);
+#pragma unroll
+        for (int j = 1; j < R; ++j) x[j] = cmul(x[j], pw[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[b * R + j] = x[j];
+    }
+  };
+
+  auto process = [&](long long chunk, bool more_after) __attribute__((always_inline)) {
     c32 v[E];
-    // ---- unpack the prefetched rows into butterfly order
+    // ---- unpack the rows into butterfly order
     if constexpr (NB1 == 1) {
 #pragma unroll
       for (int i = 0; i < NRAW; ++i) {
@@ -320,116 +409,25 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
       for (int e = 0; e < E; ++e) v[e] = make_float2(v[e].y, v[e].x);
     }
 
-    // ---- the next chunk's loads go out now
-    const long long next = chunk + gridDim.x;
-    if (next < nchunks) issue_loads(next, pre);
+    if constexpr (P::PREFETCH) {
+      // the next chunk's loads go out now and land while this chunk is computed
+      const long long next = chunk + gridDim.x;
+      if (next < nchunks) issue_loads(next, pre);
+    }
 
     if constexpr (MODE != kModeCopy) {
-      // ================= first pass =================
-#pragma unroll
-      for (int b = 0; b < NB1; ++b) {
-        c32 x[R1];
-#pragma unroll
-        for (int j = 0; j < R1; ++j) x[j] = v[b * R1 + j];
-        dft<R1>(x);
-        c32 pw[R1];
-        twiddle_powers<R1>(fresh<P::HOIST>(w1[b]), pw);
-#pragma unroll
-        for (int j = 1; j < R1; ++j) x[j] = cmul(x[j], pw[j]);
-#pragma unroll
-        for (int j = 0; j < R1; ++j) v[b * R1 + j] = x[j];
-      }
-
-      if constexpr (MODE == kModeFFT) {
-        // ---- exchange 1: write Y1[tr][k1][c]
-#pragma unroll
-        for (int b = 0; b < NB1; ++b) {
-          using W = PadWalk<P::PS1, P::PW1, C1, R1>;
-          const int base = b1_tr[b] * N + b1_c[b];
-          const int slot0 = pad_idx<P::PS1, P::PW1>(base);
-#pragma unroll
-          for (int k1 = 0; k1 < R1; ++k1) {
-            // the column index c is not a multiple of R1*C1, so only whole-period strides are affine here
-            const int s = W::kWhole ? slot0 + k1 * W::kStep : pad_idx<P::PS1, P::PW1>(base + k1 * C1);
-            lds[s] = v[b * R1 + k1];
-          }
-        }
-        __syncthreads();
-      }
-
+      using I1 = std::integral_constant<int, R1>;
+      using I2 = std::integral_constant<int, R2>;
+      using IL = std::integral_constant<int, RL>;
+      butterflies(v, I1{}, w1);
       if constexpr (P::PASSES == 3) {
-        // ================= middle pass =================
-#pragma unroll
-        for (int b = 0; b < NB2; ++b) {
-          c32 x[R2];
-          if constexpr (MODE == kModeFFT) {
-            using W = PadWalk<P::PS1, P::PW1, R3, R2>;
-            const int base = b2_tr[b] * N + b2_k1[b] * C1 + b2_n3[b];
-            const int slot0 = pad_idx<P::PS1, P::PW1>(base);
-#pragma unroll
-            for (int n2 = 0; n2 < R2; ++n2) {
-              const int s = W::kWhole ? slot0 + n2 * W::kStep : pad_idx<P::PS1, P::PW1>(base + n2 * R3);
-              x[n2] = lds[s];
-            }
-          } else {
-#pragma unroll
-            for (int n2 = 0; n2 < R2; ++n2) x[n2] = v[b * R2 + n2];
-          }
-          dft<R2>(x);
-          c32 pw[R2];
-          twiddle_powers<R2>(fresh<P::HOIST>(w2[b]), pw);
-#pragma unroll
-          for (int j = 1; j < R2; ++j) x[j] = cmul(x[j], pw[j]);
-#pragma unroll
-          for (int j = 0; j < R2; ++j) v[b * R2 + j] = x[j];
-        }
-        if constexpr (MODE == kModeFFT) {
-          __syncthreads();  // every wave has read exchange 1 before it is overwritten
-          // ---- exchange 2: write Y2[tr][k2][k1][n3]
-#pragma unroll
-          for (int b = 0; b < NB2; ++b) {
-            using W = PadWalk<P::PS2, P::PW2, R1 * R3, R2>;
-            const int base = b2_tr[b] * N + b2_k1[b] * R3 + b2_n3[b];
-            const int slot0 = pad_idx<P::PS2, P::PW2>(base);
-#pragma unroll
-            for (int k2 = 0; k2 < R2; ++k2) {
-              const int s = W::kWhole ? slot0 + k2 * W::kStep : pad_idx<P::PS2, P::PW2>(base + k2 * (R1 * R3));
-              lds[s] = v[b * R2 + k2];
-            }
-          }
-          __syncthreads();
-        }
+        if constexpr (MODE == kModeFFT) exchange(v, ex1_wslot, ex1_rslot_mid, I1{}, I2{}, false);
+        butterflies(v, I2{}, w2);
+        if constexpr (MODE == kModeFFT) exchange(v, ex2_wslot, ex2_rslot, I2{}, IL{}, true);
+      } else {
+        if constexpr (MODE == kModeFFT) exchange(v, ex1_wslot, ex1_rslot_last, I1{}, IL{}, false);
       }
-
-      // ================= last pass =================
-#pragma unroll
-      for (int b = 0; b < NBL; ++b) {
-        c32 x[RL];
-        if constexpr (MODE == kModeFFT) {
-          if constexpr (P::PASSES == 3) {
-            // butterfly q = k1 + R1*k2 reads Y2[tr][k2][k1][n3], n3 = 0..R3-1 (stride 1)
-            using W = PadWalk<P::PS2, P::PW2, 1, R3>;
-            const int k1 = bl_q[b] % R1, k2 = bl_q[b] / R1;
-            const int base = bl_tr[b] * N + k2 * (R1 * R3) + k1 * R3;
-            const int slot0 = pad_idx<P::PS2, P::PW2>(base);
-#pragma unroll
-            for (int n3 = 0; n3 < R3; ++n3) x[n3] = lds[W::slot(base, slot0, n3)];
-          } else {
-            // butterfly q = k1 reads Y1[tr][k1][n2], n2 = 0..R2-1 (stride 1)
-            using W = PadWalk<P::PS1, P::PW1, 1, R2>;
-            const int base = bl_tr[b] * N + bl_q[b] * C1;
-            const int slot0 = pad_idx<P::PS1, P::PW1>(base);
-#pragma unroll
-            for (int n2 = 0; n2 < R2; ++n2) x[n2] = lds[W::slot(base, slot0, n2)];
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < RL; ++j) x[j] = v[b * RL + j];
-        }
-        dft<RL>(x);
-#pragma unroll
-        for (int j = 0; j < RL; ++j) v[b * RL + j] = x[j];
-      }
+      butterflies(v, IL{}, static_cast<const c32*>(nullptr));
     }
 
     if constexpr (!FWD) {
@@ -458,14 +456,25 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
         }
       }
     }
-    if constexpr (MODE == kModeFFT) __syncthreads();  // exchange buffer is free for the next chunk
+    // the exchange buffer is reused by the next chunk of this workgroup
+    if (MODE == kModeFFT && more_after) __syncthreads();
   };
 
-  long long chunk = blockIdx.x;
-  if (chunk >= nchunks) return;
-  issue_loads(chunk, pre);
-  process(chunk);
-  for (chunk += gridDim.x; chunk < nchunks; chunk += gridDim.x) process(chunk);
+  if constexpr (P::PREFETCH) {
+    // Software pipeline. The first trip is written out ahead of the loop: both ways into the loop
+    // then carry "loads, then stores" in flight, and the wait for the prefetched rows is a counted
+    // vmcnt that leaves the previous chunk's stores outstanding.
+    process(chunk, true);
+    for (chunk += gridDim.x; chunk < nchunks; chunk += gridDim.x) process(chunk, true);
+  } else {
+    for (;;) {
+      const long long next = chunk + gridDim.x;
+      process(chunk, next < nchunks);
+      if (next >= nchunks) break;
+      chunk = next;
+      issue_loads(chunk, pre);
+    }
+  }
 }
 
 }  // namespace tfft

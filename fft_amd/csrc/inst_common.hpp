@@ -5,11 +5,20 @@
 
 namespace tfft {
 
-template <class P, class IO, bool WITH_MODES>
+// mode 3 (kModeAlt) runs the alternative plan PALT of the same length, for A/B timing.
+enum : int { kModeAlt = 3 };
+
+template <class P, class IO, bool WITH_MODES, class PALT = void>
 bool entry_for(bool forward, int mode, KernelEntry* out) {
   if (mode == kModeFFT) {
     *out = forward ? make_entry<P, IO, true, kModeFFT>() : make_entry<P, IO, false, kModeFFT>();
     return true;
+  }
+  if constexpr (!std::is_void_v<PALT>) {
+    if (mode == kModeAlt) {
+      *out = forward ? make_entry<PALT, IO, true, kModeFFT>() : make_entry<PALT, IO, false, kModeFFT>();
+      return true;
+    }
   }
   if constexpr (WITH_MODES) {
     if (!forward) return false;

@@ -10,16 +10,47 @@
 
 namespace tfft {
 
-//                      N      E   R1  R2  R3  WG   PS1 PW1 PS2 PW2
-using Plan64 = Plan<64, 16, 16, 4, 1, 256, 5, 1, 0, 0>;
-using Plan128 = Plan<128, 16, 16, 8, 1, 256, 5, 1, 0, 0>;
-using Plan256 = Plan<256, 16, 16, 16, 1, 256, 5, 1, 0, 0>;
-using Plan512 = Plan<512, 16, 16, 8, 4, 256, 5, 4, 5, 1>;
-using Plan1024 = Plan<1024, 16, 16, 16, 4, 256, 4, 1, 5, 1>;
-using Plan2048 = Plan<2048, 16, 16, 16, 8, 256, 4, 1, 5, 1>;
-using Plan4096 = Plan<4096, 16, 16, 16, 16, 256, 4, 1, 5, 1>;
-using Plan8192 = Plan<8192, 32, 32, 16, 16, 256, 4, 1, 5, 1>;
-using Plan16384 = Plan<16384, 32, 32, 32, 16, 512, 9, 16, 5, 1>;
+// Two exchange forms exist per length: whole complex words through an 8-byte-per-point buffer
+// ("Full": fewer barriers, ~34 KiB of LDS for 4096 points, 4 workgroups per CU) and real parts
+// then imaginary parts through a 4-byte-per-point buffer ("Split": twice the barriers, half the
+// LDS, 6-8 workgroups per CU). The default of each length is the one that measured faster on
+// MI355X at 2^28 points; the other stays reachable as the A/B plan (tfft_set_option("mode", 3)).
+//
+//                           N      E   R1  R2  R3  WG   PS1 PW1 PS2 PW2 MINW FLAGS
+using Plan64Full = Plan<64, 16, 16, 4, 1, 256, 5, 1, 0, 0>;
+using Plan128Full = Plan<128, 16, 16, 8, 1, 256, 5, 1, 0, 0>;
+using Plan256Full = Plan<256, 16, 16, 16, 1, 256, 5, 1, 0, 0>;
+using Plan512Full = Plan<512, 16, 16, 8, 4, 256, 5, 4, 5, 1>;
+using Plan1024Full = Plan<1024, 16, 16, 16, 4, 256, 4, 1, 5, 1>;
+using Plan2048Full = Plan<2048, 16, 16, 16, 8, 256, 4, 1, 5, 1>;
+using Plan4096Full = Plan<4096, 16, 16, 16, 16, 256, 4, 1, 5, 1>;
+using Plan8192Full = Plan<8192, 32, 32, 16, 16, 256, 4, 1, 5, 1>;
+using Plan16384Full = Plan<16384, 32, 32, 32, 16, 512, 9, 16, 5, 1>;
+
+using Plan64Split = Plan<64, 16, 16, 4, 1, 256, 5, 1, 0, 0, 6, kFlagSplit>;
+using Plan128Split = Plan<128, 16, 16, 8, 1, 256, 5, 1, 0, 0, 6, kFlagSplit>;
+using Plan256Split = Plan<256, 16, 16, 16, 1, 256, 5, 1, 0, 0, 5, kFlagSplit>;
+using Plan512Split = Plan<512, 16, 16, 8, 4, 256, 5, 4, 5, 1, 6, kFlagSplit>;
+using Plan1024Split = Plan<1024, 16, 16, 16, 4, 256, 6, 4, 5, 1, 6, kFlagSplit>;
+using Plan2048Split = Plan<2048, 16, 16, 16, 8, 256, 7, 8, 5, 1, 5, kFlagSplit>;
+using Plan4096Split = Plan<4096, 16, 16, 16, 16, 256, 8, 16, 5, 1, 6, kFlagSplit>;
+using Plan8192Split = Plan<8192, 32, 32, 16, 16, 256, 8, 16, 5, 1, 4, kFlagSplit>;
+using Plan16384Split = Plan<16384, 32, 32, 32, 16, 512, 5, 1, 5, 1, 4, kFlagSplit>;
+
+// default / A-B alternative per length
+using Plan64 = Plan64Full;        using Plan64Alt = Plan64Split;
+using Plan128 = Plan128Full;      using Plan128Alt = Plan128Split;
+using Plan256 = Plan256Full;      using Plan256Alt = Plan256Split;
+using Plan512 = Plan512Split;     using Plan512Alt = Plan512Full;
+using Plan1024 = Plan1024Full;    using Plan1024Alt = Plan1024Split;
+using Plan2048 = Plan2048Split;   using Plan2048Alt = Plan2048Full;
+using Plan4096 = Plan4096Split;   using Plan4096Alt = Plan4096Full;
+using Plan8192 = Plan8192Full;    using Plan8192Alt = Plan8192Split;
+using Plan16384 = Plan16384Split; using Plan16384Alt = Plan16384Full;
+
+// A resident, software-pipelined walk of the batch (prefetches the next chunk's rows); measured
+// slower than one workgroup per chunk on MI355X and kept for that comparison only.
+using Plan4096Resident = Plan<4096, 16, 16, 16, 16, 256, 4, 1, 5, 1, 1, kFlagPrefetch>;
 
 // What the host needs to launch one instantiation.
 struct KernelEntry {
@@ -53,7 +84,7 @@ KernelEntry make_entry() {
   e.radix[0] = P::R1;
   e.radix[1] = P::R2;
   e.radix[2] = P::R3;
-  e.lds_bytes = P::LDS_ELEMS * (int)sizeof(float2);
+  e.lds_bytes = P::LDS_BYTES;
   return e;
 }
 

@@ -176,6 +176,37 @@ def test_full_size_properties(n, batch):
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("n", ALL_N)
+def test_alternative_plans_vs_oracle(oracle_mod, n):
+    """mode 3 selects the A/B plan of a length (the other LDS exchange form: split real / imaginary
+    rounds vs whole complex words); a small resident grid makes workgroups loop over chunks."""
+    batch = 3 * 256 * max(1, 4096 // n) + 5
+    x = synth.uniform_complex(batch, n, seed=n + 99)
+    try:
+        fft_amd.set_option("mode", 3)
+        fft_amd.set_option("grid_blocks_per_cu", 1)
+        for forward in (True, False):
+            got, stored = run(x, "fp32", forward)
+            err = oracle_mod.rel_l2(got, oracle_mod.fft(stored, forward))
+            assert err <= 2e-6, f"n={n} forward={forward} rel_l2={err:.3e}"
+    finally:
+        fft_amd.set_option("mode", 0)
+        fft_amd.set_option("grid_blocks_per_cu", 0)
+
+
+def test_resident_grid_matches_one_shot():
+    # the same kernel walked by a resident grid (each workgroup loops over chunks) is bit-identical
+    n, batch = 1024, 5000
+    x = synth.uniform_complex(batch, n, seed=21)
+    a, _ = run(x, "fp32", True)
+    try:
+        fft_amd.set_option("grid_blocks_per_cu", 1)
+        b, _ = run(x, "fp32", True)
+    finally:
+        fft_amd.set_option("grid_blocks_per_cu", 0)
+    assert np.array_equal(a, b)
+
+
 def test_linearity():
     n, batch = 2048, 33
     a = synth.uniform_complex(batch, n, seed=1)

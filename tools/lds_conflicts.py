@@ -12,6 +12,7 @@ The script searches the one-level padding  phys(i) = i + (i >> PS) * PW  per exc
 prints the cheapest conflict-free (or least-conflicting) choice with the smallest LDS size.
 
 Usage: python tools/lds_conflicts.py            # table for every shipped configuration
+       python tools/lds_conflicts.py --split    # same for the split (real, then imaginary) exchange
 """
 import itertools
 import sys
@@ -22,16 +23,22 @@ def swz(tid):
     return (tid & ~63) | ((tid & 31) << 1) | ((tid >> 5) & 1)
 
 
+SPLIT = False  # True: exchanges move 4-byte halves (ds_write_b32 / ds_read_b32, 2 x 32 lanes, 32 banks)
+
+
 def group_cost(addrs, nbanks):
-    """addrs: element (8-byte) indices of the lanes of one lane group."""
+    """addrs: element indices of the lanes of one lane group (8-byte elements, 4-byte when SPLIT)."""
     per_bank = {}
     for a in addrs:
-        dw = 2 * a  # dword address of the low half; an 8-byte word covers banks dw, dw+1
+        dw = a if SPLIT else 2 * a  # an 8-byte word covers banks dw, dw+1
         per_bank.setdefault(dw % nbanks, set()).add(a)
     return max(len(s) for s in per_bank.values())
 
 
 def instr_cost(addrs64, kind):
+    if SPLIT:
+        groups = [addrs64[g * 32:(g + 1) * 32] for g in range(2)]
+        return sum(group_cost(g, 32) for g in groups), 2
     if kind == "w":
         groups = [addrs64[g * 16:(g + 1) * 16] for g in range(4)]
         return sum(group_cost(g, 32) for g in groups), 4
@@ -139,7 +146,7 @@ def search(cfg, wfn, rfn, label):
     for ps, pw in cands:
         pad = make_pad(ps, pw)
         size = pad(total - 1) + 1
-        if size * 8 > 160 * 1024:
+        if size * (4 if SPLIT else 8) > 160 * 1024:
             continue
         wc, wb = price(cfg, wfn, "w", pad)
         rc, rb = price(cfg, rfn, "r", pad)
@@ -149,7 +156,7 @@ def search(cfg, wfn, rfn, label):
         if best is None or rec < best:
             best = rec
     _, ps, pw, size, wf, rf = best
-    print(f"  {label}: PS={ps} PW={pw} lds_elems={size} ({size * 8} B)  write x{wf:.2f}  read x{rf:.2f}")
+    print(f"  {label}: PS={ps} PW={pw} lds_elems={size} ({size * (4 if SPLIT else 8)} B)  write x{wf:.2f}  read x{rf:.2f}")
     return ps, pw, size
 
 
@@ -167,6 +174,8 @@ CONFIGS = [
 
 
 def main():
+    global SPLIT
+    SPLIT = "--split" in sys.argv
     for N, E, R, WG in CONFIGS:
         cfg = Cfg(N, E, R, WG)
         print(f"N={N} E={E} R={R} WG={WG} TPB={cfg.TPB}")
