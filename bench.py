@@ -96,6 +96,7 @@ def main():
     import torch
 
     import fft_amd
+    from fft_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,13 +136,13 @@ def main():
         if not args.out_of_place and done % RESCALE_EVERY == 0:
             x.mul_(float(n) ** (-RESCALE_EVERY / 2.0))
 
+    def sync():
+        torch.cuda.synchronize(dev)
+
     for _ in range(args.warmup):
         step()
         keep_finite()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    sharding.barrier(dist, sync)
 
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -151,20 +152,13 @@ def main():
         step()
         ends[i].record(stream)
         keep_finite()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    sharding.barrier(dist, sync)
     wall = time.perf_counter() - t0
 
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
-    if dist:
-        t = torch.tensor([wall, kernel_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = t[0].item(), t[1].item()
+    wall, kernel_ms = sharding.max_over_ranks([wall, kernel_ms], dist, dev)
 
     ms_per_step = wall / args.steps * 1e3
-    flops_per_step = 5.0 * n * math.log2(n) * batch * world
     bytes_per_launch = BYTES_PER_POINT * n * batch
     achieved = bytes_per_launch / (kernel_ms * 1e-3) * 1e-9
 
@@ -172,7 +166,7 @@ def main():
         info = fft_amd.plan_info("fp32", n)
         line = {
             "metric": "batched 1D C2C FFT GFLOP/s (5NlogN) + % HBM roofline, N=4096 fp32",
-            "value": round(flops_per_step / (ms_per_step * 1e-3) * 1e-9, 1),
+            "value": round(sharding.aggregate_gflops(n, batch, world, ms_per_step * 1e-3), 1),
             "unit": "GFLOP/s",
             "n_gpus": world,
             "steps": args.steps,
