@@ -114,7 +114,7 @@ void run_one(const Args& a, int n) {
   const long long batch = a.points / n;
   const size_t total = (size_t)n * batch;
   // validation runs on a bounded prefix so the host-side check stays short
-  const long long vbatch = std::min<long long>(batch, (1ll << 22) / n + 3);
+  const long long vbatch = std::min<long long>(batch, n >= (1 << 20) ? 1 : (1ll << 22) / n + 3);
   const size_t vtotal = (size_t)n * vbatch;
   const bool scaled = !std::is_same_v<T, float>;
 
@@ -184,6 +184,7 @@ void run_one(const Args& a, int n) {
   std::ostringstream radix;
   radix << info.radix[0] << "x" << info.radix[1];
   if (info.radix[2] > 1) radix << "x" << info.radix[2];
+  if (n > 16384) radix << " sweeps";
 
   tfft_set_option("mode", 0);
   thunderfft::check(tfft_exec_c2c(thunderfft::dtype_code<T>(), n, 1, d_val, d_val_out, vbatch, s), "validate");

@@ -5,6 +5,7 @@
 // (thunderfft/include/thunderfft/detail/thunderfft_impl_kernel.cuh:6-30).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,6 +18,7 @@
 
 #include "../../include/thunderfft_c.h"
 #include "plans.hpp"
+#include "tile_plans.hpp"
 
 namespace {
 
@@ -44,6 +46,21 @@ struct DevicePlan {
   int cu_count = 0;
 };
 
+// Multi-pass plan of one large transform N = f[0]*f[1][*f[2]] (fp32 only): every factor is a
+// tile-kernel length; sweeps 0..nf-2 are strided column sweeps with four-step twiddles of the
+// enclosing length m[i], the last sweep reads contiguous rows and writes natural order.
+struct BigPlan {
+  int nf = 0;
+  int f[3] = {0, 0, 0};
+  float2* tw_f[3] = {nullptr, nullptr, nullptr};  // W_f^j tables of the factors
+  float2* hi[2] = {nullptr, nullptr};             // four-step tables of sweeps 0 and 1
+  float2* lo[2] = {nullptr, nullptr};
+  int shift[2] = {0, 0};
+  unsigned long long m[2] = {0, 0};
+  float4* work = nullptr;  // scratch for `work_batch` transforms
+  long long work_batch = 1;
+};
+
 struct Options {
   long long grid_blocks_per_cu = 0;
   long long mode = 0;
@@ -53,7 +70,57 @@ struct Options {
 
 std::mutex g_mu;
 std::map<std::tuple<int, int, int>, DevicePlan> g_plans;  // (device, dtype, n)
+std::map<std::tuple<int, int>, BigPlan> g_big;             // (device, n), fp32
 Options g_opt;
+
+constexpr int kMaxLdsN = 16384;       // longest transform one workgroup holds
+constexpr int kMaxBigLog2 = 30;       // longest multi-pass transform
+
+int ilog2(long long n) {
+  int l = 0;
+  while ((1LL << l) < n) ++l;
+  return ((1LL << l) == n) ? l : -1;
+}
+
+// Factors of 2^lg into 2 or 3 tile lengths (2^6 .. 2^10), as even as possible, longest last
+// (the last sweep reads contiguous rows of that length).
+bool factor_big(int lg, int* nf, int f[3]) {
+  if (lg <= 14 || lg > kMaxBigLog2) return false;
+  const int parts = (lg <= 20) ? 2 : 3;
+  int e[3] = {0, 0, 0};
+  for (int i = 0; i < parts; ++i) e[i] = lg / parts + (i >= parts - lg % parts ? 1 : 0);
+  for (int i = 0; i < parts; ++i)
+    if (e[i] < 6 || e[i] > 10) return false;
+  *nf = parts;
+  for (int i = 0; i < 3; ++i) f[i] = (i < parts) ? (1 << e[i]) : 1;
+  return true;
+}
+
+std::vector<float2> unit_roots(unsigned long long m, unsigned long long count, unsigned long long step) {
+  std::vector<float2> h(count);
+  for (unsigned long long j = 0; j < count; ++j) {
+    const unsigned long long idx = (j * step) & (m - 1);
+    const double a = -2.0 * M_PI * (double)idx / (double)m;
+    h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  return h;
+}
+
+hipError_t upload(const std::vector<float2>& h, float2** d) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(d), sizeof(float2) * h.size());
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*d, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice);
+}
+
+void free_big(BigPlan& p) {
+  for (int i = 0; i < 3; ++i) if (p.tw_f[i]) (void)hipFree(p.tw_f[i]);
+  for (int i = 0; i < 2; ++i) {
+    if (p.hi[i]) (void)hipFree(p.hi[i]);
+    if (p.lo[i]) (void)hipFree(p.lo[i]);
+  }
+  if (p.work) (void)hipFree(p.work);
+  p = BigPlan();
+}
 
 bool lookup(int dtype, int n, bool forward, int mode, tfft::KernelEntry* e) {
   switch (dtype) {
@@ -86,10 +153,50 @@ const char* tfft_last_error(void) { return g_err.c_str(); }
 
 int tfft_is_supported(int dtype, int n, int forward) {
   tfft::KernelEntry e;
-  return lookup(dtype, n, forward != 0, 0, &e) ? 1 : 0;
+  if (lookup(dtype, n, forward != 0, 0, &e)) return 1;
+  int nf, f[3];
+  return (dtype == TFFT_F32 && n > kMaxLdsN && factor_big(ilog2(n), &nf, f)) ? 1 : 0;
+}
+
+static int initialize_big(int n) {
+  int nf, f[3];
+  if (!factor_big(ilog2(n), &nf, f)) return fail(TFFT_ERR_UNSUPPORTED, "tfft_initialize: no multi-pass plan for n=%d", n);
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto key = std::make_tuple(dev, n);
+  if (g_big.count(key)) return TFFT_OK;
+  BigPlan p;
+  p.nf = nf;
+  hipError_t e = hipSuccess;
+  unsigned long long m = (unsigned long long)n;
+  for (int i = 0; i < nf && e == hipSuccess; ++i) {
+    p.f[i] = f[i];
+    e = upload(unit_roots((unsigned long long)f[i], (unsigned long long)f[i], 1), &p.tw_f[i]);
+    if (i < nf - 1 && e == hipSuccess) {
+      // sweep i multiplies by W_m^(q*k), m = length of the transform this sweep starts
+      p.m[i] = m;
+      const int lg = ilog2((long long)m);
+      p.shift[i] = (lg + 1) / 2;
+      e = upload(unit_roots(m, 1ull << p.shift[i], 1), &p.lo[i]);
+      if (e == hipSuccess) e = upload(unit_roots(m, m >> p.shift[i], 1ull << p.shift[i]), &p.hi[i]);
+      m /= (unsigned long long)f[i];
+    }
+  }
+  // scratch: at least one transform, and enough (2^26 points, 512 MiB) that batches of shorter
+  // transforms go through in few launches
+  p.work_batch = std::max<long long>(1, (1LL << 26) / n);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p.work), sizeof(float2) * (size_t)n * (size_t)p.work_batch);
+  if (e != hipSuccess) {
+    free_big(p);
+    return fail(TFFT_ERR_HIP, "tfft_initialize(n=%d): %s", n, hipGetErrorString(e));
+  }
+  g_big[key] = p;
+  return TFFT_OK;
 }
 
 int tfft_initialize(int dtype, int n) {
+  if (dtype == TFFT_F32 && n > kMaxLdsN) return initialize_big(n);
   tfft::KernelEntry fwd, inv;
   if (!lookup(dtype, n, true, 0, &fwd) || !lookup(dtype, n, false, 0, &inv))
     return fail(TFFT_ERR_UNSUPPORTED, "tfft_initialize: no kernel for %s n=%d", dtype_name(dtype), n);
@@ -136,6 +243,13 @@ int tfft_finalize(int dtype) {
       ++it;
     }
   }
+  if (dtype == TFFT_F32) {
+    for (auto& kv : g_big) {
+      (void)hipSetDevice(std::get<0>(kv.first));
+      free_big(kv.second);
+    }
+    g_big.clear();
+  }
   (void)hipSetDevice(cur);
   return rc;
 }
@@ -143,6 +257,21 @@ int tfft_finalize(int dtype) {
 int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info) {
   if (!info) return fail(TFFT_ERR_INVALID, "tfft_get_plan_info: null info");
   tfft::KernelEntry e;
+  if (dtype == TFFT_F32 && n > kMaxLdsN) {
+    int nf, f[3];
+    if (!factor_big(ilog2(n), &nf, f))
+      return fail(TFFT_ERR_UNSUPPORTED, "tfft_get_plan_info: no multi-pass plan for n=%d", n);
+    tfft::TileEntry t;
+    tfft::lookup_tile(f[nf - 1], true, tfft::kTileOutCol, &t);
+    info->n = n;
+    info->threads_per_block = t.threads;
+    info->transforms_per_block = t.tpb;  // short transforms per tile of the last sweep
+    info->points_per_thread = t.n * t.tpb / t.threads;
+    for (int i = 0; i < 3; ++i) info->radix[i] = f[i];  // sweep lengths
+    info->lds_bytes = t.lds_bytes;
+    info->blocks_per_cu = 0;
+    return TFFT_OK;
+  }
   if (!lookup(dtype, n, true, 0, &e))
     return fail(TFFT_ERR_UNSUPPORTED, "tfft_get_plan_info: no kernel for %s n=%d", dtype_name(dtype), n);
   info->n = e.n;
@@ -172,6 +301,74 @@ int tfft_set_option(const char* key, long long value) {
   return TFFT_OK;
 }
 
+// One large transform per batch entry: 2 or 3 sweeps of tile kernels through the plan's scratch.
+static int exec_big(int n, int forward, const void* d_in, void* d_out, long long batch, hipStream_t s) {
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  BigPlan p;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_big.find(std::make_tuple(dev, n));
+    if (it == g_big.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
+    p = it->second;
+  }
+  const bool fwd = forward != 0;
+  constexpr int kSweep = tfft::kTileInCol | tfft::kTileOutCol | tfft::kTileTwiddle;
+  for (long long b = 0; b < batch; b += p.work_batch) {
+    const long long group = std::min<long long>(p.work_batch, batch - b);  // transforms per launch
+    const float4* src = static_cast<const float4*>(d_in) + b * (long long)(n / 2);
+    float4* dst = static_cast<float4*>(d_out) + b * (long long)(n / 2);
+    long long rest = n;  // points of the transform the current sweep starts: f[i] * ... * f[nf-1]
+    long long done = 1;  // product of the lengths already transformed
+    for (int i = 0; i < p.nf; ++i) {
+      const bool last = (i == p.nf - 1);
+      tfft::TileEntry t;
+      if (!tfft::lookup_tile(p.f[i], fwd, last ? tfft::kTileOutCol : kSweep, &t))
+        return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c: no tile kernel of length %d", p.f[i]);
+      tfft::TileArgs a{};
+      a.in = (i == 0) ? src : p.work;
+      a.out = last ? dst : p.work;
+      a.tw = p.tw_f[i];
+      a.in_bi = a.out_bi = n;
+      const long long cols = rest / p.f[i];  // columns of this sweep inside one enclosing transform
+      if (!last) {
+        // column sweep: `done` enclosing transforms of `rest` points, each with `cols` columns
+        a.tw_hi = p.hi[i];
+        a.tw_lo = p.lo[i];
+        a.tw_shift = p.shift[i];
+        a.tw_mmask = p.m[i] - 1;
+        a.na = (int)done;
+        a.nb = (int)(cols / t.tpb);
+        a.in_a = a.out_a = rest;
+        a.in_b = a.out_b = t.tpb;
+        a.in_stride = a.out_stride = cols;
+        a.q_a = 0;
+        a.q_b = t.tpb;
+      } else {
+        // rows of f[last] contiguous points; row index = (k_0, ..., k_{nf-2}) in sweep order.
+        // Tile over adjacent k_0 (row stride n / f[0]); natural position of output k_last of that
+        // row is k_0 + f[0]*k_1 + ... + (n / f[last]) * k_last.
+        const long long rows_rest = done / p.f[0];  // rows per k_0 value: f[1] * ... * f[nf-2]
+        a.na = (int)rows_rest;
+        a.nb = p.f[0] / t.tpb;
+        a.in_a = p.f[i];
+        a.in_b = (long long)t.tpb * (n / p.f[0]);
+        a.in_stride = n / p.f[0];
+        a.out_a = p.f[0];
+        a.out_b = t.tpb;
+        a.out_stride = done;
+      }
+      a.ntiles = group * a.na * a.nb;
+      t.launch(a, s);
+      TFFT_HIP(hipGetLastError());
+      rest = cols;
+      done *= p.f[i];
+    }
+  }
+  return TFFT_OK;
+}
+
 int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
                   void* stream) {
   if (batch < 0) return fail(TFFT_ERR_INVALID, "tfft_exec_c2c: negative batch %lld", batch);
@@ -179,6 +376,11 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
   if (!d_in || !d_out) return fail(TFFT_ERR_INVALID, "tfft_exec_c2c: null device pointer");
   if ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u)
     return fail(TFFT_ERR_INVALID, "tfft_exec_c2c: buffers must be 16-byte aligned");
+  if (dtype == TFFT_F32 && n > kMaxLdsN) {
+    const int rc = exec_big(n, forward, d_in, d_out, batch, static_cast<hipStream_t>(stream));
+    if (rc == TFFT_OK && g_opt.sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return rc;
+  }
   Options opt;
   DevicePlan plan;
   int dev = 0;

@@ -1,0 +1,83 @@
+"""GPU parity tests of the multi-pass path (N > 16384, fp32): strided tile sweeps with four-step
+twiddles, natural order in and out. The reference has no transform longer than 4096."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+import fft_amd  # noqa: E402
+from fft_amd import synth  # noqa: E402
+
+
+def run_big(x, forward=True, inplace=False):
+    n = x.shape[-1]
+    d = torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(x.shape + (2,))).to("cuda")
+    out = d if inplace else torch.full_like(d, float("nan"))
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    fft_amd.ThunderFFT_global(d, out, x.shape[0], n, forward)
+    torch.cuda.synchronize()
+    a = out.cpu().numpy().astype(np.float64)
+    return a[..., 0] + 1j * a[..., 1]
+
+
+@pytest.mark.parametrize("lg", (15, 16, 17, 18, 19, 20, 21, 22))
+@pytest.mark.parametrize("forward", (True, False))
+def test_big_vs_oracle(oracle_mod, lg, forward):
+    n = 1 << lg
+    batch = 2 if lg <= 18 else 1
+    x = synth.uniform_complex(batch, n, seed=lg)
+    got = run_big(x, forward)
+    err = oracle_mod.rel_l2(got, oracle_mod.fft(x, forward))
+    assert err <= 1e-5, f"n=2^{lg} forward={forward} rel_l2={err:.3e}"
+    assert err <= 3e-6, f"accuracy regressed: n=2^{lg} rel_l2={err:.3e}"
+
+
+@pytest.mark.parametrize("lg", (24, 26, 27))
+def test_very_big_vs_fp64_fft_and_roundtrip(lg):
+    n = 1 << lg
+    g = torch.Generator(device="cuda").manual_seed(lg)
+    x = torch.rand(1, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    X = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x, X, 1, n, True)
+    back = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(X, back, 1, n, False)
+    torch.cuda.synchronize()
+    ref = torch.fft.fft(torch.view_as_complex(x.double().contiguous()), dim=-1)
+    got = torch.view_as_complex(X.double().contiguous())
+    err = (torch.linalg.vector_norm(got - ref) / torch.linalg.vector_norm(ref)).item()
+    assert err <= 1e-5, f"n=2^{lg} rel_l2={err:.3e}"
+    rt = (torch.linalg.vector_norm((back / n - x).double()) / torch.linalg.vector_norm(x.double())).item()
+    assert rt <= 1e-5, rt
+    del ref, got, X, back, x
+    fft_amd.ThunderFFTFinalize("fp32")  # releases the scratch of the big plans
+    torch.cuda.empty_cache()
+
+
+def test_big_in_place_and_tone(oracle_mod):
+    n = 1 << 17
+    x = synth.uniform_complex(1, n, seed=3)
+    a = run_big(x, True, inplace=False)
+    b = run_big(x, True, inplace=True)
+    assert np.array_equal(a, b)
+    # a single tone lands in one bin
+    k0 = 12345
+    t = np.exp(2j * np.pi * k0 * np.arange(n) / n).astype(np.complex64)[None]
+    X = run_big(t, True)
+    assert abs(X[0, k0] - n) < 1e-2 * n
+    X[0, k0] = 0
+    assert np.max(np.abs(X)) < 1e-3 * n
+
+
+def test_big_supported_table():
+    for lg in range(15, 31):
+        assert fft_amd.is_supported("fp32", 1 << lg, True)
+    assert not fft_amd.is_supported("fp32", 1 << 31 if False else 3 << 20, True)
+    assert not fft_amd.is_supported("fp16", 1 << 20, True)
+    info = fft_amd.plan_info("fp32", 1 << 26)
+    prod = 1
+    for r in info["radix"]:
+        prod *= r
+    assert prod == 1 << 26

@@ -184,5 +184,92 @@ def main():
             search(cfg, cfg.ex2_write, cfg.ex2_read, "exchange 2")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--tile" not in sys.argv:
     main()
+
+
+# ---------------------------------------------------------------------------------------------
+# Tile kernels (fft_tile_kernel.hpp): two passes, LDS layout [element][transform]
+# ---------------------------------------------------------------------------------------------
+class TileCfg:
+    def __init__(self, N, E, R1, R2, TPB):
+        self.N, self.E, self.R1, self.R2, self.TPB = N, E, R1, R2, TPB
+        self.WG = TPB * N // E
+        self.C1, self.CL = N // R1, N // R2
+
+    def ids(self, tid, NB):
+        if NB == 1:
+            return [swz(tid)]
+        out = []
+        for pi in range(NB // 2):
+            g = 2 * (tid + self.WG * pi)
+            out += [g, g + 1]
+        return out
+
+    def write(self, tid, in_col):
+        out = []
+        for g in self.ids(tid, self.E // self.R1):
+            tr, c = (g % self.TPB, g // self.TPB) if in_col else (g // self.C1, g % self.C1)
+            out.append([(k1 * self.C1 + c) * self.TPB + tr for k1 in range(self.R1)])
+        return out
+
+    def read(self, tid, out_col):
+        out = []
+        for g in self.ids(tid, self.E // self.R2):
+            tr, q = (g % self.TPB, g // self.TPB) if out_col else (g // self.CL, g % self.CL)
+            out.append([(q * self.C1 + n2) * self.TPB + tr for n2 in range(self.R2)])
+        return out
+
+
+def price_tile(cfg, per_thread, kind, pad):
+    nb, ne = len(per_thread[0]), len(per_thread[0][0])
+    tot = base = 0
+    for w in range(cfg.WG // 64):
+        for b in range(nb):
+            for e in range(ne):
+                c, b0 = instr_cost([pad(per_thread[w * 64 + l][b][e]) for l in range(64)], kind)
+                tot += c
+                base += b0
+    return tot / base
+
+
+TILE_CONFIGS = [
+    (64, 16, 16, 4, 64),
+    (128, 16, 16, 8, 32),
+    (256, 16, 16, 16, 16),
+    (256, 16, 16, 16, 32),
+    (512, 32, 16, 32, 16),
+    (1024, 32, 32, 32, 16),
+]
+
+
+def tile_main():
+    global SPLIT
+    for split in (False, True):
+        SPLIT = split
+        print(f"==== tile kernels, {'split' if split else 'full'} exchange")
+        for N, E, R1, R2, TPB in TILE_CONFIGS:
+            cfg = TileCfg(N, E, R1, R2, TPB)
+            total = N * TPB
+            w_col = [cfg.write(t, True) for t in range(cfg.WG)]
+            w_row = [cfg.write(t, False) for t in range(cfg.WG)]
+            r_col = [cfg.read(t, True) for t in range(cfg.WG)]
+            best = None
+            for ps, pw in [(0, 0)] + [(ps, pw) for ps in range(2, 12) for pw in (1, 2, 4, 8, 16)]:
+                pad = make_pad(ps, pw)
+                size = pad(total - 1) + 1
+                if size * (4 if split else 8) > 160 * 1024:
+                    continue
+                wc, wr, rc = (price_tile(cfg, w_col, "w", pad), price_tile(cfg, w_row, "w", pad),
+                              price_tile(cfg, r_col, "r", pad))
+                score = 2 * rc + 0.6 * max(wc, 1.5) + 0.6 * max(wr, 1.5) + 1e-3 * size / total
+                rec = (score, ps, pw, size, wc, wr, rc)
+                if best is None or rec < best:
+                    best = rec
+            _, ps, pw, size, wc, wr, rc = best
+            print(f"N={N} E={E} R=({R1},{R2}) TPB={TPB} WG={cfg.WG}: PS={ps} PW={pw} "
+                  f"lds={size * (4 if split else 8)} B  write(col-in) x{wc:.2f}  write(row-in) x{wr:.2f}  read(col-out) x{rc:.2f}")
+
+
+if __name__ == "__main__" and "--tile" in sys.argv:
+    tile_main()
