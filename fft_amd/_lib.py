@@ -13,6 +13,7 @@ SYMBOLS = (
     "tfft_is_supported",
     "tfft_get_plan_info",
     "tfft_set_option",
+    "tfft_fourstep_twiddle",
     "tfft_last_error",
 )
 
@@ -53,6 +54,7 @@ def load():
     lib.tfft_is_supported.argtypes = [i, i, i]
     lib.tfft_get_plan_info.argtypes = [i, i, ctypes.POINTER(PlanInfo)]
     lib.tfft_set_option.argtypes = [cp, ll]
+    lib.tfft_fourstep_twiddle.argtypes = [i, vp, ll, ll, ll, ll, ll, i, vp]
     lib.tfft_last_error.argtypes = []
     lib.tfft_last_error.restype = cp
     for name in SYMBOLS:

@@ -147,7 +147,22 @@ const char* dtype_name(int dtype) {
 
 }  // namespace
 
+extern "C" int tfft_fourstep_twiddle_launch(void* d_data, long long rows, long long cols, long long row0,
+                                            long long col0, long long n, int forward, void* stream);
+
 extern "C" {
+
+int tfft_fourstep_twiddle(int dtype, void* d_data, long long rows, long long cols, long long row0, long long col0,
+                          long long n, int forward, void* stream) {
+  if (dtype != TFFT_F32) return fail(TFFT_ERR_UNSUPPORTED, "tfft_fourstep_twiddle: fp32 only");
+  if (!d_data || rows < 0 || cols < 0 || (cols & 1) || n <= 0 || row0 < 0 || col0 < 0 ||
+      (reinterpret_cast<uintptr_t>(d_data) & 15u))
+    return fail(TFFT_ERR_INVALID, "tfft_fourstep_twiddle: bad arguments (cols must be even, buffer 16-byte aligned)");
+  if (rows == 0 || cols == 0) return TFFT_OK;
+  const int e = tfft_fourstep_twiddle_launch(d_data, rows, cols, row0, col0, n, forward, stream);
+  if (e != 0) return fail(TFFT_ERR_HIP, "tfft_fourstep_twiddle: %s", hipGetErrorString((hipError_t)e));
+  return TFFT_OK;
+}
 
 const char* tfft_last_error(void) { return g_err.c_str(); }
 

@@ -44,7 +44,9 @@ int tfft_finalize(int dtype);
  * (thunderfft.cuh:98-102; body detail/thunderfft_impl_kernel.cuh:6-30). n is a run-time
  * argument here. The launch is asynchronous on `stream` (a hipStream_t, may be NULL); the
  * reference's trailing cudaStreamSynchronize is left to the caller (the C++ wrapper does it).
- * n is a power of two in 64 ... 16384: one LDS-resident kernel per launch. */
+ * n is a power of two: 64 ... 16384 run one LDS-resident kernel per launch (all three element
+ * types); 2^15 ... 2^30 (fp32) run 2 or 3 strided sweeps through a scratch buffer that
+ * tfft_initialize allocated (four-step; the reference has no transform beyond 4096). */
 int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
                   void* stream);
 
@@ -75,6 +77,14 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *                          results on purpose; they price the memory pattern and the butterflies)
  *   "sync"               : 1 = synchronise the stream after every launch like the reference */
 int tfft_set_option(const char* key, long long value);
+
+/* Twiddle step between the two halves of a four-step transform that run as separate batched
+ * calls (distributed transforms: local FFTs, all-to-all, local FFTs): element (r, c) of the
+ * row-major [rows][cols] block is multiplied by W_n^((row0 + r) * (col0 + c)), W_n = exp(-2 pi i / n),
+ * or by its conjugate when forward == 0. cols must be even. No counterpart in the reference,
+ * whose longest transform fits one block (detail/thunderfft_impl.cuh:14-32). fp32 only. */
+int tfft_fourstep_twiddle(int dtype, void* d_data, long long rows, long long cols, long long row0,
+                          long long col0, long long n, int forward, void* stream);
 
 const char* tfft_last_error(void);
 

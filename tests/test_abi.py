@@ -36,9 +36,25 @@ def test_supported_table():
         for n in fft_amd.SUPPORTED_N:
             assert fft_amd.is_supported(code, n, True)
             assert fft_amd.is_supported(code, n, False)  # the reference lacks inverse 512 / 2048
-        for n in (0, 1, 32, 96, 1000, 32768):
-            assert not fft_amd.is_supported(code, n, True)
+        for n in (0, 1, 32, 96, 1000, 3 << 20, 1 << 31):
+            assert not fft_amd.is_supported(code, n if n < (1 << 31) else (1 << 31) - 1, True)
+        # beyond one workgroup's LDS: multi-pass plans, fp32 only
+        assert fft_amd.is_supported(code, 1 << 15, True) == (code == fft_amd.TFFT_F32)
+        assert fft_amd.is_supported(code, 1 << 30, False) == (code == fft_amd.TFFT_F32)
     assert not fft_amd.is_supported(7, 1024, True)
+
+
+def test_big_plan_factors():
+    import fft_amd
+
+    for lg in range(15, 31):
+        info = fft_amd.plan_info("fp32", 1 << lg)
+        prod = 1
+        for r in info["radix"]:
+            assert 64 <= r <= 1024
+            prod *= r
+        assert prod == 1 << lg
+        assert len(info["radix"]) == (2 if lg <= 20 else 3)
 
 
 def test_plan_info_geometry():
