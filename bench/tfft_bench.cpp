@@ -53,6 +53,7 @@ struct Args {
   int mode = 0;
   int grid = 0;
   int extra_lds = 0;
+  long long skew = 0;  // bytes added to the output buffer's address (out of place only)
   bool csv = false, ndjson = false, hipfft = true;
 };
 
@@ -137,7 +138,11 @@ void run_one(const Args& a, int n) {
   CHECK_HIP(hipMalloc(&d_val, sizeof(vec2_t<T>) * vtotal));
   CHECK_HIP(hipMalloc(&d_val_out, sizeof(vec2_t<T>) * vtotal));
   CHECK_HIP(hipMalloc(&d_perf, sizeof(vec2_t<T>) * total));
-  if (!a.inplace) CHECK_HIP(hipMalloc(&d_perf_out, sizeof(vec2_t<T>) * total));
+  vec2_t<T>* d_perf_out_alloc = nullptr;
+  if (!a.inplace) {
+    CHECK_HIP(hipMalloc(&d_perf_out_alloc, sizeof(vec2_t<T>) * total + (size_t)a.skew));
+    d_perf_out = reinterpret_cast<vec2_t<T>*>(reinterpret_cast<char*>(d_perf_out_alloc) + a.skew);
+  }
   CHECK_HIP(hipMemcpy(d_val, hs.data(), sizeof(vec2_t<T>) * vtotal, hipMemcpyHostToDevice));
   // timing buffer: the validation pattern repeated (values do not matter for timing, but keep them finite)
   for (size_t off = 0; off < total; off += vtotal) {
@@ -224,7 +229,7 @@ void run_one(const Args& a, int n) {
   CHECK_HIP(hipFree(d_val));
   CHECK_HIP(hipFree(d_val_out));
   CHECK_HIP(hipFree(d_perf));
-  if (d_perf_out) CHECK_HIP(hipFree(d_perf_out));
+  if (d_perf_out_alloc) CHECK_HIP(hipFree(d_perf_out_alloc));
   CHECK_HIP(hipStreamDestroy(s));
 }
 
@@ -248,6 +253,7 @@ int main(int argc, char** argv) {
     else if (k == "--mode") a.mode = std::stoi(val());
     else if (k == "--grid") a.grid = std::stoi(val());
     else if (k == "--extra-lds") a.extra_lds = std::stoi(val());
+    else if (k == "--skew") a.skew = std::stoll(val());
     else if (k == "--csv") a.csv = true;
     else if (k == "--ndjson") a.ndjson = true;
     else if (k == "--no-hipfft") a.hipfft = false;

@@ -136,7 +136,7 @@ struct StoreBF16 {
 // ---------------------------------------------------------------------------------------
 // Plan constants shared by host and device.
 // ---------------------------------------------------------------------------------------
-enum : int { kFlagPrefetch = 1, kFlagSplit = 2, kFlagHoist = 4 };
+enum : int { kFlagPrefetch = 1, kFlagSplit = 2, kFlagHoist = 4, kFlagMfmaMid = 8 };
 
 template <int N_, int E_, int R1_, int R2_, int R3_, int WG_, int PS1_, int PW1_, int PS2_, int PW2_, int MINW_ = 1,
           int FLAGS_ = 0>
@@ -153,6 +153,12 @@ struct Plan {
   static constexpr bool PREFETCH = (FLAGS_ & kFlagPrefetch) != 0;
   static constexpr bool SPLIT = (FLAGS_ & kFlagSplit) != 0;
   static constexpr bool HOIST = (FLAGS_ & kFlagHoist) != 0;
+  // MFMA_MID: (N = 16*16*16 only) the middle radix-16 pass runs on the matrix cores: per k1 the
+  //           16x16 complex DFT matrix times the 16x16 block Y1[k1][m1][m2] is two
+  //           v_mfma_f32_16x16x32_f16 (real and imaginary rows of the real-ified matrix, K = 32 =
+  //           16 points x (re, im)); exchange 1 then carries fp16 pairs. For 16-bit storage only:
+  //           the fp16 operands cost ~5e-4 relative accuracy.
+  static constexpr bool MFMA_MID = (FLAGS_ & kFlagMfmaMid) != 0;
   static constexpr int PASSES = (R3 > 1) ? 3 : 2;
   static constexpr int RL = (R3 > 1) ? R3 : R2;  // radix of the last pass
   static constexpr int T = N / E;                // threads per transform
@@ -166,7 +172,11 @@ struct Plan {
   static constexpr int LDS1 = pad1(TOTAL - 1) + 1;
   static constexpr int LDS2 = (PASSES == 3) ? pad2(TOTAL - 1) + 1 : 0;
   static constexpr int LDS_ELEMS = LDS1 > LDS2 ? LDS1 : LDS2;
-  static constexpr int LDS_BYTES = LDS_ELEMS * (SPLIT ? 4 : 8);
+  // fp16 exchange of the MFMA middle pass: rows (k1, m2) of 16 half2 (m1 fastest), 80-byte pitch
+  static constexpr int MFMA_PITCH = 20;  // dwords; 16-byte aligned rows, 2-way write conflicts at most
+  static constexpr int LDS_MFMA = MFMA_MID ? (N / 16) * MFMA_PITCH * 4 : 0;
+  static constexpr int LDS_BYTES = (LDS_ELEMS * (SPLIT ? 4 : 8)) > LDS_MFMA ? (LDS_ELEMS * (SPLIT ? 4 : 8)) : LDS_MFMA;
+  static_assert(!MFMA_MID || (R1 == 16 && R2 == 16 && R3 == 16 && E == 16 && WG == 256), "MFMA middle pass: N = 4096 plan only");
   static_assert(R1 * R2 * R3 == N, "radices must multiply to N");
   static_assert(T * TPB == WG && TPB >= 1, "workgroup must hold whole transforms");
   static_assert(E % R1 == 0 && E % R2 == 0 && E % RL == 0, "radix must divide points per thread");
@@ -199,6 +209,9 @@ __device__ __forceinline__ int walk_slot(int base, int base_slot, int e) {
 }
 
 enum : int { kModeFFT = 0, kModeCopy = 1, kModeNoLds = 2 };
+
+typedef _Float16 mfma_h8 __attribute__((ext_vector_type(8)));
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
 
 // Identity that the optimiser cannot see through unless HOIST: stops loop-invariant code
 // motion from parking every power of a twiddle in registers for the whole batch loop.
@@ -314,6 +327,26 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
     for (int b = 0; b < NB2; ++b) w2[b] = tw[b2_n3[b] * R1];
   }
 
+  // ---- matrix-core middle pass: this lane's fragments of the real-ified DFT-16 matrix and its
+  // four output twiddles. Lane l = (g = l >> 4, i = l & 15) supplies A[row i][k = 8g .. 8g+7] with
+  // k = 2*m1 + part, holds B rows m1 = 4g .. 4g+3 of column m2 = i, and receives rows k2 = 4g .. 4g+3.
+  const int mf_g = (tid >> 4) & 3, mf_i = tid & 15;
+  mfma_h8 mf_are, mf_aim;
+  c32 mf_tw[4];
+  if constexpr (P::MFMA_MID) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int m1 = 4 * mf_g + jj;
+      const c32 f = tw[((mf_i * m1) & 15) * (N / 16)];  // W_16^(k2*m1) = (cos, -sin)
+      mf_are[2 * jj] = (_Float16)f.x;       // Yr += cos * Xr
+      mf_are[2 * jj + 1] = (_Float16)(-f.y);  //     + sin * Xi
+      mf_aim[2 * jj] = (_Float16)f.y;       // Yi += -sin * Xr
+      mf_aim[2 * jj + 1] = (_Float16)f.x;   //     + cos * Xi
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mf_tw[j] = tw[(mf_i * (4 * mf_g + j)) * R1];  // W_256^(m2*k2)
+  }
+
   // ---- LDS slots. Writer element (b, j) and reader element (b, j) of each exchange.
   // exchange 1 holds Y1[tr][k1][c] at logical index tr*N + k1*C1 + c
   auto ex1_wslot = [&](int b, int k1) {
@@ -420,7 +453,36 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
       using I2 = std::integral_constant<int, R2>;
       using IL = std::integral_constant<int, RL>;
       butterflies(v, I1{}, w1);
-      if constexpr (P::PASSES == 3) {
+      if constexpr (P::MFMA_MID && MODE == kModeFFT) {
+        // ---- exchange 1 as fp16 pairs: thread (column c = 16*m1 + m2) writes Y1[k1][c], k1 = 0..15
+        unsigned* const ldsh = reinterpret_cast<unsigned*>(lds_raw);
+        {
+          const int m1 = b1_c[0] >> 4, m2 = b1_c[0] & 15;
+#pragma unroll
+          for (int k1 = 0; k1 < 16; ++k1) {
+            const __half2 h = __float22half2_rn(v[k1]);
+            ldsh[(k1 * 16 + m2) * P::MFMA_PITCH + m1] = *reinterpret_cast<const unsigned*>(&h);
+          }
+        }
+        __syncthreads();
+        // ---- middle pass on the matrix cores: wave w owns k1 = 4w .. 4w+3
+        const int wave = tid >> 6;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k1 = 4 * wave + t;
+          const mfma_h8 bfrag = *reinterpret_cast<const mfma_h8*>(&ldsh[(k1 * 16 + mf_i) * P::MFMA_PITCH + 4 * mf_g]);
+          mfma_f4 cr = {0.f, 0.f, 0.f, 0.f}, ci = {0.f, 0.f, 0.f, 0.f};
+          cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(mf_are, bfrag, cr, 0, 0, 0);
+          ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(mf_aim, bfrag, ci, 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[t * 4 + j] = cmul(make_float2(cr[j], ci[j]), mf_tw[j]);
+        }
+        // ---- exchange 2: lane (g, i) of wave w holds Y2[k1 = 4w+t][k2 = 4g+j][n3 = i] in v[4t + j]
+        auto ex2_wslot_mfma = [&](int t, int j) {
+          return pad_idx<P::PS2, P::PW2>((4 * mf_g + j) * (R1 * R3) + (4 * wave + t) * R3 + mf_i);
+        };
+        exchange(v, ex2_wslot_mfma, ex2_rslot, std::integral_constant<int, 4>{}, IL{}, true);
+      } else if constexpr (P::PASSES == 3) {
         if constexpr (MODE == kModeFFT) exchange(v, ex1_wslot, ex1_rslot_mid, I1{}, I2{}, false);
         butterflies(v, I2{}, w2);
         if constexpr (MODE == kModeFFT) exchange(v, ex2_wslot, ex2_rslot, I2{}, IL{}, true);

@@ -90,63 +90,66 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_tile_kernel(const TileArgs
   constexpr int NG1 = (NB1 == 1) ? 1 : NB1 / 2;
   constexpr int LPG1 = NRAW / NG1;
   int b1_tr[NB1], b1_c[NB1];
-  long long ld_base[NG1];  // element offset of load 0 of the group (both points of the pair)
+  // Offsets inside a tile stay below 2^31 points (the longest enclosing transform is 2^30), so
+  // they are kept in 32 bits; only the tile base is 64-bit.
+  unsigned ld_base[NG1];  // point offset of load 0 of the group (both points of the pair)
+  const unsigned in_stride = (unsigned)a.in_stride, out_stride = (unsigned)a.out_stride;
   auto decode1 = [&](int g, int& tr, int& c) {
     if constexpr (IN_COL) { tr = g % TPB; c = g / TPB; } else { tr = g / C1; c = g % C1; }
   };
-  auto in_addr = [&](int tr, long long e) -> long long {
-    return IN_COL ? e * a.in_stride + tr : tr * a.in_stride + e;
+  auto in_addr = [&](int tr, unsigned e) -> unsigned {
+    return IN_COL ? e * in_stride + (unsigned)tr : (unsigned)tr * in_stride + e;
   };
   if constexpr (NB1 == 1) {
     decode1(pair_swizzle(tid), b1_tr[0], b1_c[0]);
     const int tr0 = IN_COL ? (b1_tr[0] & ~1) : b1_tr[0];
     const int c0 = IN_COL ? b1_c[0] : (b1_c[0] & ~1);
-    ld_base[0] = in_addr(tr0, (long long)hi * (R1 / 2) * C1 + c0);
+    ld_base[0] = in_addr(tr0, (unsigned)(hi * (R1 / 2) * C1 + c0));
   } else {
 #pragma unroll
     for (int pi = 0; pi < NB1 / 2; ++pi) {
       const int g = 2 * (tid + WG * pi);
       decode1(g, b1_tr[2 * pi], b1_c[2 * pi]);
       decode1(g + 1, b1_tr[2 * pi + 1], b1_c[2 * pi + 1]);
-      ld_base[pi] = in_addr(b1_tr[2 * pi], b1_c[2 * pi]);
+      ld_base[pi] = in_addr(b1_tr[2 * pi], (unsigned)b1_c[2 * pi]);
     }
   }
-  const long long row_step = IN_COL ? (long long)C1 * a.in_stride : (long long)C1;  // next row of the same column
+  const unsigned row_step = IN_COL ? (unsigned)C1 * in_stride : (unsigned)C1;  // next row of the same column
   raw pre[NRAW];
   {
-    const raw* src = a.in;
+    const raw* src = a.in + (in_base >> 1);
 #pragma unroll
     for (int g = 0; g < NG1; ++g)
 #pragma unroll
-      for (int i = 0; i < LPG1; ++i) pre[g * LPG1 + i] = IO::load(src + ((in_base + ld_base[g] + i * row_step) >> 1));
+      for (int i = 0; i < LPG1; ++i) pre[g * LPG1 + i] = IO::load(src + ((ld_base[g] + (unsigned)i * row_step) >> 1));
   }
 
   // ---- last pass butterflies (tr, q) and their stores
   constexpr int NGL = (NBL == 1) ? 1 : NBL / 2;
   constexpr int SPGL = NRAW / NGL;
   int bl_tr[NBL], bl_q[NBL];
-  long long st_base[NGL];
+  unsigned st_base[NGL];
   auto decodeL = [&](int g, int& tr, int& q) {
     if constexpr (OUT_COL) { tr = g % TPB; q = g / TPB; } else { tr = g / CL; q = g % CL; }
   };
-  auto out_addr = [&](int tr, long long e) -> long long {
-    return OUT_COL ? e * a.out_stride + tr : tr * a.out_stride + e;
+  auto out_addr = [&](int tr, unsigned e) -> unsigned {
+    return OUT_COL ? e * out_stride + (unsigned)tr : (unsigned)tr * out_stride + e;
   };
   if constexpr (NBL == 1) {
     decodeL(pair_swizzle(tid), bl_tr[0], bl_q[0]);
     const int tr0 = OUT_COL ? (bl_tr[0] & ~1) : bl_tr[0];
     const int q0 = OUT_COL ? bl_q[0] : (bl_q[0] & ~1);
-    st_base[0] = out_addr(tr0, (long long)hi * (R2 / 2) * CL + q0);
+    st_base[0] = out_addr(tr0, (unsigned)(hi * (R2 / 2) * CL + q0));
   } else {
 #pragma unroll
     for (int pi = 0; pi < NBL / 2; ++pi) {
       const int g = 2 * (tid + WG * pi);
       decodeL(g, bl_tr[2 * pi], bl_q[2 * pi]);
       decodeL(g + 1, bl_tr[2 * pi + 1], bl_q[2 * pi + 1]);
-      st_base[pi] = out_addr(bl_tr[2 * pi], bl_q[2 * pi]);
+      st_base[pi] = out_addr(bl_tr[2 * pi], (unsigned)bl_q[2 * pi]);
     }
   }
-  const long long out_row_step = OUT_COL ? (long long)CL * a.out_stride : (long long)CL;
+  const unsigned out_row_step = OUT_COL ? (unsigned)CL * out_stride : (unsigned)CL;
 
   // ---- inter-pass twiddle bases W_n^c
   c32 w1[NB1];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_tile_kernel(const TileArgs
 
   // ---- store
   {
-    raw* dst = a.out;
+    raw* dst = a.out + (out_base >> 1);
 #pragma unroll
     for (int g = 0; g < NGL; ++g)
 #pragma unroll
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_tile_kernel(const TileArgs
         } else {
           r = IO::pack(v[(2 * g) * R2 + i], v[(2 * g + 1) * R2 + i]);
         }
-        IO::store(dst + ((out_base + st_base[g] + i * out_row_step) >> 1), r);
+        IO::store(dst + ((st_base[g] + (unsigned)i * out_row_step) >> 1), r);
       }
   }
 }

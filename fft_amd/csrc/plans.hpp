@@ -37,11 +37,22 @@ using Plan4096Split = Plan<4096, 16, 16, 16, 16, 256, 8, 16, 5, 1, 6, kFlagSplit
 using Plan8192Split = Plan<8192, 32, 32, 16, 16, 256, 8, 16, 5, 1, 4, kFlagSplit>;
 using Plan16384Split = Plan<16384, 32, 32, 32, 16, 512, 5, 1, 5, 1, 4, kFlagSplit>;
 
+// 16-bit storage, N = 4096: middle radix-16 pass on the matrix cores (fp16 operands, fp32 accumulate)
+using Plan4096Mfma = Plan<4096, 16, 16, 16, 16, 256, 8, 16, 5, 1, 4, kFlagSplit | kFlagMfmaMid>;
+
+// "Wide" three-pass forms of the short lengths: radix 4 or 8 first and last, so that the row
+// segments of the first-pass loads and last-pass stores are N/4 or N/8 points long (128 ... 512
+// bytes) instead of N/16 (32 bytes at N = 64), at the price of a second LDS exchange.
+using Plan64Wide = Plan<64, 16, 4, 4, 4, 256, 5, 4, 5, 1>;
+using Plan128Wide = Plan<128, 16, 4, 8, 4, 256, 5, 4, 5, 1>;
+using Plan256Wide = Plan<256, 16, 4, 16, 4, 256, 4, 1, 5, 1>;
+using Plan512Wide = Plan<512, 16, 8, 16, 4, 256, 6, 4, 5, 1, 5, kFlagSplit>;
+
 // default / A-B alternative per length
-using Plan64 = Plan64Full;        using Plan64Alt = Plan64Split;
-using Plan128 = Plan128Full;      using Plan128Alt = Plan128Split;
-using Plan256 = Plan256Full;      using Plan256Alt = Plan256Split;
-using Plan512 = Plan512Split;     using Plan512Alt = Plan512Full;
+using Plan64 = Plan64Wide;        using Plan64Alt = Plan64Full;
+using Plan128 = Plan128Full;      using Plan128Alt = Plan128Wide;
+using Plan256 = Plan256Full;      using Plan256Alt = Plan256Wide;
+using Plan512 = Plan512Split;     using Plan512Alt = Plan512Wide;
 using Plan1024 = Plan1024Full;    using Plan1024Alt = Plan1024Split;
 using Plan2048 = Plan2048Split;   using Plan2048Alt = Plan2048Full;
 using Plan4096 = Plan4096Split;   using Plan4096Alt = Plan4096Full;

@@ -161,6 +161,10 @@ def search(cfg, wfn, rfn, label):
 
 
 CONFIGS = [
+    (64, 16, (4, 4, 4), 256),
+    (128, 16, (4, 8, 4), 256),
+    (256, 16, (4, 16, 4), 256),
+    (512, 16, (8, 16, 4), 256),
     (64, 16, (16, 4), 256),
     (128, 16, (16, 8), 256),
     (256, 16, (16, 16), 256),
