@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the HIP library and the oracle in-tree if a fresh checkout has neither (hipcc
+    cross-compiles gfx950 without a GPU; about half a minute). The GPU box gets prebuilt files."""
+    import subprocess
+
+    lib = os.path.join(ROOT, "fft_amd", "lib", "libthunderfft_hip.so")
+    ora = os.path.join(ROOT, "oracle", "liboracle_dft.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        subprocess.check_call(["make", "-C", ROOT, "-j8", "lib", "oracle"], stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle
