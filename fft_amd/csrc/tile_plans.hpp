@@ -6,9 +6,9 @@
 namespace tfft {
 
 //                         N     E   R1  R2  TPB  PS PW MINW FLAGS
-using Tile64 = TilePlan<64, 16, 16, 4, 64, 5, 1, 4, 0>;
-using Tile128 = TilePlan<128, 16, 16, 8, 32, 4, 1, 4, 0>;
-using Tile256 = TilePlan<256, 16, 16, 16, 16, 4, 1, 4, 0>;
+using Tile64 = TilePlan<64, 16, 16, 4, 128, 5, 1, 4, kFlagSplit>;
+using Tile128 = TilePlan<128, 16, 16, 8, 64, 5, 1, 4, kFlagSplit>;
+using Tile256 = TilePlan<256, 16, 16, 16, 32, 5, 1, 4, kFlagSplit>;
 using Tile512 = TilePlan<512, 32, 16, 32, 16, 5, 1, 3, kFlagSplit>;
 using Tile1024 = TilePlan<1024, 32, 32, 32, 16, 5, 1, 4, kFlagSplit>;
 

@@ -238,6 +238,8 @@ def price_tile(cfg, per_thread, kind, pad):
 
 
 TILE_CONFIGS = [
+    (64, 16, 16, 4, 128),
+    (128, 16, 16, 8, 64),
     (64, 16, 16, 4, 64),
     (128, 16, 16, 8, 32),
     (256, 16, 16, 16, 16),
