@@ -109,4 +109,31 @@ __device__ __forceinline__ void twiddle_powers(c32 w, c32 (&pw)[R]) {
   }
 }
 
+// x[j] *= w^j for j = 1..R-1. Up to radix 16 the powers come from one chain; above that a full
+// chain would keep R/2 powers alive at once, so j = 8a + b uses two short chains,
+// w^j = (w^8)^a * w^b: 16 live powers instead of 32 or 64 for the same number of multiplies.
+template <int R>
+__device__ __forceinline__ void apply_twiddles(c32 (&x)[R], c32 w) {
+  if constexpr (R <= 16) {
+    c32 pw[R];
+    twiddle_powers<R>(w, pw);
+#pragma unroll
+    for (int j = 1; j < R; ++j) x[j] = cmul(x[j], pw[j]);
+  } else {
+    constexpr int RH = R / 8;
+    c32 lo[8], hi[RH];
+    twiddle_powers<8>(w, lo);
+    twiddle_powers<RH>(csqr(lo[4]), hi);
+#pragma unroll
+    for (int a = 0; a < RH; ++a) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        if (a == 0 && b == 0) continue;
+        const c32 f = (a == 0) ? lo[b] : (b == 0) ? hi[a] : cmul(hi[a], lo[b]);
+        x[8 * a + b] = cmul(x[8 * a + b], f);
+      }
+    }
+  }
+}
+
 }  // namespace tfft

@@ -409,12 +409,7 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
 #pragma unroll
       for (int j = 0; j < R; ++j) x[j] = v[b * R + j];
       dft<R>(x);
-      if (w != nullptr) {
-        c32 pw[R];
-        twiddle_powers<R>(fresh<P::HOIST>(w[b]), pw);
-#pragma unroll
-        for (int j = 1; j < R; ++j) x[j] = cmul(x[j], pw[j]);
-      }
+      if (w != nullptr) apply_twiddles<R>(x, fresh<P::HOIST>(w[b]));
 #pragma unroll
       for (int j = 0; j < R; ++j) v[b * R + j] = x[j];
     }

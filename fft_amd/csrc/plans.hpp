@@ -48,13 +48,28 @@ using Plan128Wide = Plan<128, 16, 4, 8, 4, 256, 5, 4, 5, 1>;
 using Plan256Wide = Plan<256, 16, 4, 16, 4, 256, 4, 1, 5, 1>;
 using Plan512Wide = Plan<512, 16, 8, 16, 4, 256, 6, 4, 5, 1, 5, kFlagSplit>;
 
+// Small-workgroup forms: 64 or 128 threads per workgroup, so one workgroup requests 8 or 16 KiB
+// at a time instead of 32 KiB (whole complex words through LDS, 8-17 KiB of it).
+using Plan64Small = Plan<64, 16, 4, 4, 4, 64, 5, 4, 5, 1>;
+using Plan128Small = Plan<128, 16, 4, 8, 4, 64, 5, 4, 5, 1>;
+using Plan256Small = Plan<256, 16, 16, 16, 1, 64, 5, 1, 0, 0>;
+using Plan256Mid = Plan<256, 16, 16, 16, 1, 128, 5, 1, 0, 0>;
+using Plan512Mid = Plan<512, 16, 16, 8, 4, 128, 5, 4, 5, 1>;
+using Plan1024Mid = Plan<1024, 16, 16, 16, 4, 128, 4, 1, 5, 1>;
+using Plan512Small = Plan<512, 16, 16, 8, 4, 64, 5, 4, 5, 1>;
+using Plan1024Small = Plan<1024, 16, 16, 16, 4, 64, 4, 1, 5, 1>;
+using Plan2048Small = Plan<2048, 16, 16, 16, 8, 128, 4, 1, 5, 1>;
+using Plan512E32 = Plan<512, 32, 16, 32, 1, 64, 6, 1, 0, 0>;
+using Plan1024E32 = Plan<1024, 32, 32, 32, 1, 64, 6, 1, 0, 0>;
+using Plan4096E64S = Plan<4096, 64, 64, 64, 1, 64, 7, 1, 0, 0, 2, kFlagSplit>;
+
 // default / A-B alternative per length
-using Plan64 = Plan64Wide;        using Plan64Alt = Plan64Full;
-using Plan128 = Plan128Full;      using Plan128Alt = Plan128Wide;
-using Plan256 = Plan256Full;      using Plan256Alt = Plan256Wide;
-using Plan512 = Plan512Split;     using Plan512Alt = Plan512Wide;
-using Plan1024 = Plan1024Full;    using Plan1024Alt = Plan1024Split;
-using Plan2048 = Plan2048Split;   using Plan2048Alt = Plan2048Full;
+using Plan64 = Plan64Small;       using Plan64Alt = Plan64Wide;
+using Plan128 = Plan128Small;     using Plan128Alt = Plan128Full;
+using Plan256 = Plan256Mid;       using Plan256Alt = Plan256Small;
+using Plan512 = Plan512E32;       using Plan512Alt = Plan512Small;
+using Plan1024 = Plan1024E32;     using Plan1024Alt = Plan1024Small;
+using Plan2048 = Plan2048Small;   using Plan2048Alt = Plan2048Split;
 using Plan4096 = Plan4096Split;   using Plan4096Alt = Plan4096Full;
 using Plan8192 = Plan8192Full;    using Plan8192Alt = Plan8192Split;
 using Plan16384 = Plan16384Split; using Plan16384Alt = Plan16384Full;
