@@ -11,19 +11,20 @@ LIBDIR     := fft_amd/lib
 BUILD      := build
 
 KERNEL_SRCS := $(CSRC)/inst_f32_a.hip $(CSRC)/inst_f32_b.hip $(CSRC)/inst_f32_c.hip \
-               $(CSRC)/inst_f16.hip $(CSRC)/inst_bf16.hip $(CSRC)/inst_tile.hip $(CSRC)/fourstep_twiddle.hip $(CSRC)/tfft_c_api.hip
+               $(CSRC)/inst_f16.hip $(CSRC)/inst_bf16.hip $(CSRC)/inst_tile.hip $(CSRC)/fourstep_twiddle.hip $(CSRC)/fft_conv.hip $(CSRC)/tfft_c_api.hip
 KERNEL_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNEL_SRCS))
 KERNEL_HDRS := $(wildcard $(CSRC)/*.hpp) include/thunderfft_c.h
 
 LIB        := $(LIBDIR)/libthunderfft_hip.so
 ORACLE     := oracle/liboracle_dft.so
 BENCH      := bench/tfft_bench
+CONVBENCH  := bench/thff_conv1d_fullfft4096
 
 .PHONY: all lib oracle bench clean
 all: lib oracle bench
 lib: $(LIB)
 oracle: $(ORACLE)
-bench: $(BENCH)
+bench: $(BENCH) $(CONVBENCH)
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(KERNEL_HDRS)
 	@mkdir -p $(BUILD)
@@ -40,5 +41,9 @@ $(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh 
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ bench/tfft_bench.cpp \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
+$(CONVBENCH): bench/thff_conv1d_fullfft4096.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ bench/thff_conv1d_fullfft4096.cpp \
+	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
 clean:
-	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH)
+	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH) $(CONVBENCH)

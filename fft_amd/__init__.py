@@ -18,4 +18,4 @@ from .api import (  # noqa: F401
     fft,
     SUPPORTED_N,
 )
-from . import synth  # noqa: F401
+from . import conv, synth  # noqa: F401

@@ -14,6 +14,8 @@ SYMBOLS = (
     "tfft_get_plan_info",
     "tfft_set_option",
     "tfft_fourstep_twiddle",
+    "tfft_conv_exec",
+    "tfft_conv_filter_layout",
     "tfft_last_error",
 )
 
@@ -55,6 +57,8 @@ def load():
     lib.tfft_get_plan_info.argtypes = [i, i, ctypes.POINTER(PlanInfo)]
     lib.tfft_set_option.argtypes = [cp, ll]
     lib.tfft_fourstep_twiddle.argtypes = [i, vp, ll, ll, ll, ll, ll, i, vp]
+    lib.tfft_conv_exec.argtypes = [i, i, i, vp, vp, vp, i, i, vp]
+    lib.tfft_conv_filter_layout.argtypes = [i, i, vp, vp, i, vp]
     lib.tfft_last_error.argtypes = []
     lib.tfft_last_error.restype = cp
     for name in SYMBOLS:

@@ -1,0 +1,67 @@
+"""Host-side mirror of the reference's fused FFT-convolution sample, above the C ABI.
+
+Reference: thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu. Its main() prepares the
+filter spectra (filter_fft_once, :412-426: forward FFT of the zero-padded, 1/N-scaled taps, then
+permute_filter_layout4096) and launches one of three fused kernels per run (run_once, :433-449).
+The same two steps are `filter_spectra` and `fft_conv` here; tensors stand in for device pointers.
+"""
+import torch
+
+from . import _lib
+from .api import ThunderFFTError, ThunderFFTInitialize, ThunderFFT_global, _check, dtype_code
+
+CONV_COMPLEX, CONV_REAL_IN, CONV_REAL_IN_OUT = 0, 1, 2
+SUPPORTED_CONV_N = (4096,)
+
+
+def _stream(t, stream):
+    return (stream or torch.cuda.current_stream(t.device)).cuda_stream
+
+
+def filter_layout(h_freq, N, stream=None):
+    """[D, N, 2] natural-order filter spectra -> the register order the fused kernel reads."""
+    if not (h_freq.is_cuda and h_freq.is_contiguous()) or h_freq.shape[-2:] != (N, 2):
+        raise ThunderFFTError(3, "filter_layout needs a contiguous device tensor [D, N, 2]")
+    D = h_freq.numel() // (2 * N)
+    out = torch.empty_like(h_freq)
+    with torch.cuda.device(h_freq.device):
+        _check(_lib.load().tfft_conv_filter_layout(dtype_code(h_freq.dtype), int(N), h_freq.data_ptr(),
+                                                   out.data_ptr(), int(D), _stream(h_freq, stream)))
+    return out
+
+
+def filter_spectra(h_time, N, stream=None):
+    """Filter taps [D, K, 2] (already scaled by 1/N if the caller wants a normalised result, as the
+    reference does at :352-361) -> register-order spectra [D, N, 2] of the same element type."""
+    D, K = h_time.shape[0], h_time.shape[1]
+    if K > N:
+        raise ThunderFFTError(3, f"filter has {K} taps, transform length is {N}")
+    padded = torch.zeros(D, N, 2, dtype=h_time.dtype, device=h_time.device)
+    padded[:, :K] = h_time
+    ThunderFFTInitialize(h_time.dtype, N)
+    spec = torch.empty_like(padded)
+    ThunderFFT_global(padded, spec, D, N, True, stream)
+    return filter_layout(spec, N, stream)
+
+
+def fft_conv(x, h_perm, N, kind=CONV_COMPLEX, out=None, stream=None):
+    """y[b, d] = IDFT_N(DFT_N(x[b, d]) * H[d]), unnormalised, in one kernel.
+
+    x: [B, D, N, 2] (complex kinds) or [B, D, N] (real-input kinds); h_perm from filter_spectra /
+    filter_layout, [D, N, 2]; result [B, D, N, 2], or [B, D, N] for CONV_REAL_IN_OUT.
+    """
+    real_in = kind in (CONV_REAL_IN, CONV_REAL_IN_OUT)
+    want = (N,) if real_in else (N, 2)
+    if not (x.is_cuda and x.is_contiguous()) or x.dim() != 2 + len(want) or tuple(x.shape[2:]) != want:
+        raise ThunderFFTError(3, f"fft_conv needs a contiguous device tensor [B, D, {', '.join(map(str, want))}]")
+    B, D = x.shape[0], x.shape[1]
+    if h_perm.shape[0] != D or h_perm.dtype != x.dtype or not h_perm.is_contiguous():
+        raise ThunderFFTError(3, "filter spectra must be contiguous [D, N, 2] of the signal's element type")
+    if out is None:
+        shape = (B, D, N) if kind == CONV_REAL_IN_OUT else (B, D, N, 2)
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    ThunderFFTInitialize(x.dtype, N)
+    with torch.cuda.device(x.device):
+        _check(_lib.load().tfft_conv_exec(dtype_code(x.dtype), int(N), int(kind), x.data_ptr(), h_perm.data_ptr(),
+                                          out.data_ptr(), int(B), int(D), _stream(x, stream)))
+    return out

@@ -1,0 +1,22 @@
+// Host-visible table of the fused FFT-convolution kernels (fft_conv.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tfft {
+
+// What the signal buffers hold: complex in and out, real in / complex out, real in and out
+// (the three kernels of the reference's sample,
+// thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:148-292).
+enum : int { kConvComplex = 0, kConvRealIn = 1, kConvRealInOut = 2 };
+
+struct ConvEntry {
+  // y[b][d] = IDFT_n( DFT_n(x[b][d]) * H[d] ), unnormalised; hp = H in the kernel's register order
+  void (*launch)(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream);
+  // hp <- h: natural-order spectra [D][n] to register order
+  void (*layout)(const void* h, void* hp, int D, hipStream_t stream);
+  int n, threads, points_per_thread, lds_bytes;
+};
+
+bool lookup_conv(int dtype, int n, int kind, ConvEntry* out);
+
+}  // namespace tfft

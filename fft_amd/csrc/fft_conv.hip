@@ -1,0 +1,124 @@
+// Fused circular convolution through the frequency domain: one workgroup per signal runs
+//   load -> forward FFT -> multiply by the filter spectrum -> inverse FFT -> store
+// with the points in registers from the first load to the last store. Built from the
+// device-level blocks of fft_block.hpp.
+//
+// Replaces the reference's thunder_conv4096_block_kernel, ..._realin and ..._realin_realout and
+// its permute_filter_layout4096 (thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:
+// 120-146, 148-292). Differences by design: fp32 arithmetic in registers for every storage type
+// (the reference multiplies and accumulates in fp16), and consecutive workgroups share a filter
+// (block -> (d, b) with b fastest), so that a filter spectrum is read from HBM once and then
+// served by L2 to the B signals that use it.
+#include "conv_plans.hpp"
+#include "fft_block.hpp"
+#include "../../include/thunderfft_c.h"
+
+namespace tfft {
+
+// 16 x 16 x 16, whole complex words through LDS (fewest barriers: the fused kernel is bound by
+// butterflies and LDS exchanges, not by HBM).
+using ConvPlan4096 = Plan<4096, 16, 16, 16, 16, 256, 4, 1, 5, 1, 4>;
+
+// Filter spectra in register order: pair j of thread t (registers 2j, 2j+1) of filter d sits at
+// raw element  d * (TPB*N/2) + j * WG + t, so one wave instruction reads consecutive raw elements.
+template <class P, class HIO>
+__global__ __launch_bounds__(P::WG) void conv_filter_layout_kernel(const typename HIO::raw* __restrict__ h,
+                                                                  typename HIO::raw* __restrict__ hp, int D) {
+  using raw = typename HIO::raw;
+  const BlockFFT<P> f(nullptr, nullptr);
+  const long long d = blockIdx.x;
+  // natural order is addressed per point: view the raw buffers as arrays of single points
+  using point = std::conditional_t<sizeof(raw) == 16, float2, unsigned>;
+  const point* src = reinterpret_cast<const point*>(h) + d * P::N;
+  point* dst = reinterpret_cast<point*>(hp) + d * (long long)(P::TPB * P::N);
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) dst[((e >> 1) * P::WG + f.tid) * 2 + (e & 1)] = src[f.index_out(e)];
+}
+
+template <class P, class IOIN, class IOOUT, class HIO>
+__global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_kernel(const typename IOIN::raw* __restrict__ x,
+                                                                  const typename HIO::raw* __restrict__ hp,
+                                                                  typename IOOUT::raw* __restrict__ y,
+                                                                  const float2* __restrict__ tw, int B, int D) {
+  static_assert(P::TPB == 1, "one signal per workgroup");
+  static_assert(BlockFFT<P>::kChainable, "first and last radix must agree");
+  constexpr int N = P::N, E = P::E;
+  __shared__ __attribute__((aligned(16))) char lds[P::LDS_BYTES];
+
+  // blocks that share a filter are adjacent: block = d * B + b, signal = b * D + d
+  const int d = blockIdx.x / B;
+  const int b = blockIdx.x - d * B;
+  const long long sig = (long long)b * D + d;
+
+  const BlockFFT<P> f(tw, lds);
+  typename IOIN::raw pre[P::NRAW];
+  f.template load<IOIN>(x + sig * (N / 2), 1, pre);
+  typename HIO::raw hraw[E / 2];
+  const typename HIO::raw* hsrc = hp + (long long)d * (N / 2) + f.tid;
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) hraw[j] = hsrc[j * P::WG];
+
+  c32 v[E];
+  f.template unpack<IOIN>(pre, v);
+  f.template transform<true>(v, false);
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) {
+    c32 h0, h1;
+    HIO::unpack(hraw[j], h0, h1);
+    v[2 * j] = cmul(v[2 * j], h0);
+    v[2 * j + 1] = cmul(v[2 * j + 1], h1);
+  }
+  f.template transform<false>(v, true);
+  f.template store<IOOUT>(y + sig * (N / 2), 1, v);
+}
+
+template <class P, class IOIN, class IOOUT, class HIO>
+void launch_conv(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
+  fft_conv_kernel<P, IOIN, IOOUT, HIO><<<dim3((unsigned)B * (unsigned)D), dim3(P::WG), 0, stream>>>(
+      static_cast<const typename IOIN::raw*>(x), static_cast<const typename HIO::raw*>(hp),
+      static_cast<typename IOOUT::raw*>(y), tw, B, D);
+}
+
+template <class P, class HIO>
+void launch_layout(const void* h, void* hp, int D, hipStream_t stream) {
+  conv_filter_layout_kernel<P, HIO><<<dim3((unsigned)D), dim3(P::WG), 0, stream>>>(
+      static_cast<const typename HIO::raw*>(h), static_cast<typename HIO::raw*>(hp), D);
+}
+
+template <class P, class IOIN, class IOOUT, class HIO>
+ConvEntry make_conv_entry() {
+  ConvEntry e;
+  e.launch = &launch_conv<P, IOIN, IOOUT, HIO>;
+  e.layout = &launch_layout<P, HIO>;
+  e.n = P::N;
+  e.threads = P::WG;
+  e.points_per_thread = P::E;
+  e.lds_bytes = P::LDS_BYTES;
+  return e;
+}
+
+template <class P>
+bool lookup_conv_plan(int dtype, int kind, ConvEntry* out) {
+  if (dtype == TFFT_F32 && kind == kConvComplex) {
+    *out = make_conv_entry<P, StoreF32, StoreF32, StoreF32>();
+    return true;
+  }
+  if (dtype == TFFT_F16) {
+    switch (kind) {
+      case kConvComplex: *out = make_conv_entry<P, StoreF16, StoreF16, StoreF16>(); return true;
+      case kConvRealIn: *out = make_conv_entry<P, StoreRealF16, StoreF16, StoreF16>(); return true;
+      case kConvRealInOut: *out = make_conv_entry<P, StoreRealF16, StoreRealF16, StoreF16>(); return true;
+      default: return false;
+    }
+  }
+  return false;
+}
+
+bool lookup_conv(int dtype, int n, int kind, ConvEntry* out) {
+  switch (n) {
+    case 4096: return lookup_conv_plan<ConvPlan4096>(dtype, kind, out);
+    default: return false;
+  }
+}
+
+}  // namespace tfft

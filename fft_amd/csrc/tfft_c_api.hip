@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/thunderfft_c.h"
+#include "conv_plans.hpp"
 #include "plans.hpp"
 #include "tile_plans.hpp"
 
@@ -430,6 +431,54 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
   e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, (unsigned)opt.extra_lds, s);
   TFFT_HIP(hipGetLastError());
   if (opt.sync) TFFT_HIP(hipStreamSynchronize(s));
+  return TFFT_OK;
+}
+
+static int conv_common(const char* who, int dtype, int n, int kind, tfft::ConvEntry* e) {
+  if (kind < TFFT_CONV_COMPLEX || kind > TFFT_CONV_REAL_IN_OUT)
+    return fail(TFFT_ERR_INVALID, "%s: unknown kind %d", who, kind);
+  if (!tfft::lookup_conv(dtype, n, kind, e))
+    return fail(TFFT_ERR_UNSUPPORTED, "%s: no fused convolution kernel for %s n=%d kind=%d", who, dtype_name(dtype), n,
+                kind);
+  return TFFT_OK;
+}
+
+int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream) {
+  tfft::ConvEntry e;
+  if (int rc = conv_common("tfft_conv_filter_layout", dtype, n, TFFT_CONV_COMPLEX, &e)) return rc;
+  if (D < 0) return fail(TFFT_ERR_INVALID, "tfft_conv_filter_layout: negative D");
+  if (D == 0) return TFFT_OK;
+  if (!d_h_freq || !d_h_perm || d_h_freq == d_h_perm)
+    return fail(TFFT_ERR_INVALID, "tfft_conv_filter_layout: null or aliased device pointers");
+  e.layout(d_h_freq, d_h_perm, D, static_cast<hipStream_t>(stream));
+  TFFT_HIP(hipGetLastError());
+  return TFFT_OK;
+}
+
+int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,
+                   void* stream) {
+  tfft::ConvEntry e;
+  if (int rc = conv_common("tfft_conv_exec", dtype, n, kind, &e)) return rc;
+  if (B < 0 || D < 0) return fail(TFFT_ERR_INVALID, "tfft_conv_exec: negative B or D");
+  if (B == 0 || D == 0) return TFFT_OK;
+  if ((long long)B * D > 0x7fffffffLL) return fail(TFFT_ERR_INVALID, "tfft_conv_exec: B * D exceeds 2^31 - 1");
+  if (!d_x || !d_h_perm || !d_y) return fail(TFFT_ERR_INVALID, "tfft_conv_exec: null device pointer");
+  if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y) | reinterpret_cast<uintptr_t>(d_h_perm)) & 15u)
+    return fail(TFFT_ERR_INVALID, "tfft_conv_exec: buffers must be 16-byte aligned");
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  DevicePlan plan;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+    if (it == g_plans.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_exec: call tfft_initialize(%s, %d) on device %d first",
+                  dtype_name(dtype), n, dev);
+    plan = it->second;
+  }
+  e.launch(d_x, d_h_perm, d_y, plan.tw, B, D, static_cast<hipStream_t>(stream));
+  TFFT_HIP(hipGetLastError());
+  if (g_opt.sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return TFFT_OK;
 }
 

@@ -86,6 +86,28 @@ int tfft_set_option(const char* key, long long value);
 int tfft_fourstep_twiddle(int dtype, void* d_data, long long rows, long long cols, long long row0,
                           long long col0, long long n, int forward, void* stream);
 
+/* Fused circular convolution of length n through the frequency domain, one kernel per call:
+ *   y[b][d] = IDFT_n( DFT_n(x[b][d]) * H[d] ),  b < B, d < D,  unnormalised (scale h by 1/n beforehand,
+ * as the reference does, sample/conv1d/conv1d_fullfft_l4096_thunder.cu:352-361).
+ * Replaces thunder_conv4096_block_kernel, thunder_conv4096_block_kernel_realin and
+ * thunder_conv4096_block_kernel_realin_realout (same file, :148-292): signals are [B][D][n]
+ * contiguous and signal (b, d) uses filter d, i.e. filter = signal index % D (:171).
+ *   kind TFFT_CONV_COMPLEX     : x and y interleaved complex of `dtype`
+ *   kind TFFT_CONV_REAL_IN     : x real (n values per signal), y interleaved complex
+ *   kind TFFT_CONV_REAL_IN_OUT : x real, y = real part of the result (exact for real filters)
+ * d_h_perm holds the D filter spectra in the kernel's register order, made by
+ * tfft_conv_filter_layout. Supported: n = 4096; fp16 (all kinds), fp32 (complex kind).
+ * Needs tfft_initialize(dtype, n). Asynchronous on `stream`; allocates nothing. */
+enum { TFFT_CONV_COMPLEX = 0, TFFT_CONV_REAL_IN = 1, TFFT_CONV_REAL_IN_OUT = 2 };
+int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,
+                   void* stream);
+
+/* Replaces permute_filter_layout4096 (sample/conv1d/conv1d_fullfft_l4096_thunder.cu:120-146):
+ * reorders D natural-order filter spectra ([D][n] interleaved complex of `dtype`, e.g. the output of
+ * tfft_exec_c2c on the zero-padded filters) into the order tfft_conv_exec reads. d_h_perm must not
+ * alias d_h_freq. */
+int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream);
+
 const char* tfft_last_error(void);
 
 #ifdef __cplusplus

@@ -9,6 +9,8 @@ from .fft_oracle import (  # noqa: F401
     fft_radix2,
     fft_numpy,
     fft,
+    circular_conv,
+    circular_conv_fft,
     rel_l2,
     max_abs_err,
 )

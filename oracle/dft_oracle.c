@@ -133,3 +133,30 @@ int oracle_fft_f32(const float* in, double* out, int n, long long batch, int sig
   free(wide);
   return rc;
 }
+
+/* Circular convolution by its definition, the reference's own validation loop
+ * (sample/conv1d/conv1d_fullfft_l4096_thunder.cu:472-483) in fp64:
+ *   y[s][n] = sum_{k < K} x[s][(n - k) mod N] * h[s % D][k]
+ * x: `signals` x n interleaved complex; h: D x K interleaved complex; y like x. The fused device
+ * kernel returns N * y when h was not pre-scaled by 1/N (unnormalised inverse, :354-356). */
+int oracle_circular_conv(const double* x, const double* h, double* y, int n, int K, long long signals, int D) {
+  if (n <= 0 || K <= 0 || K > n || signals < 0 || D <= 0) return 1;
+  for (long long s = 0; s < signals; ++s) {
+    const double* xs = x + 2 * (size_t)s * (size_t)n;
+    const double* hs = h + 2 * (size_t)(s % D) * (size_t)K;
+    double* ys = y + 2 * (size_t)s * (size_t)n;
+    for (int i = 0; i < n; ++i) {
+      double re = 0.0, im = 0.0;
+      for (int k = 0; k < K; ++k) {
+        int idx = i - k;
+        if (idx < 0) idx += n;
+        const double xr = xs[2 * idx], xi = xs[2 * idx + 1];
+        re += xr * hs[2 * k] - xi * hs[2 * k + 1];
+        im += xr * hs[2 * k + 1] + xi * hs[2 * k];
+      }
+      ys[2 * i] = re;
+      ys[2 * i + 1] = im;
+    }
+  }
+  return 0;
+}

@@ -38,6 +38,9 @@ def _load():
             fn = getattr(lib, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
+        lib.oracle_circular_conv.restype = ctypes.c_int
+        lib.oracle_circular_conv.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
         _lib = lib
     return _lib
 
@@ -75,6 +78,34 @@ def fft_numpy(x, forward=True):
 def fft(x, forward=True):
     """The oracle the GPU path is compared with."""
     return fft_radix2(x, forward)
+
+
+def circular_conv(x, h):
+    """y[s] = x[s] (*) h[s % D], circular, by the O(N K) definition in fp64 -- the reference's own
+    validation loop (thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:472-483).
+    x: [signals, N] complex, h: [D, K] complex; returns complex128 [signals, N]."""
+    x2 = np.ascontiguousarray(np.asarray(x).astype(np.complex128))
+    h2 = np.ascontiguousarray(np.asarray(h).astype(np.complex128))
+    signals, n = x2.shape
+    D, K = h2.shape
+    y = np.empty_like(x2)
+    rc = _load().oracle_circular_conv(x2.ctypes.data, h2.ctypes.data, y.ctypes.data, n, K, signals, D)
+    if rc != 0:
+        raise ValueError(f"oracle_circular_conv failed with code {rc}")
+    return y
+
+
+def circular_conv_fft(x, h):
+    """The same result through the oracle's own transforms: IDFT(DFT(x) * DFT(h padded)) / N."""
+    x2 = np.asarray(x).astype(np.complex128)
+    h2 = np.asarray(h).astype(np.complex128)
+    signals, n = x2.shape
+    D, K = h2.shape
+    hp = np.zeros((D, n), dtype=np.complex128)
+    hp[:, :K] = h2
+    H = fft_radix2(hp, True)
+    X = fft_radix2(x2, True)
+    return fft_radix2(X * H[np.arange(signals) % D], False) / n
 
 
 def rel_l2(test, ref):

@@ -1,0 +1,142 @@
+"""GPU parity tests of the fused FFT convolution (tfft_conv_exec / tfft_conv_filter_layout), called
+through the C ABI, against the fp64 circular-convolution oracle.
+
+The oracle restates the reference's own validation loop
+(thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:472-483); inputs follow its main():
+signals uniform in [0, 1), taps uniform in [0, 1) scaled by 1/N (:346-361). Tolerances: relative L2
+<= 1e-5 for fp32 storage, <= 1e-2 for fp16 storage.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+import fft_amd  # noqa: E402
+from fft_amd import conv  # noqa: E402
+
+N = 4096
+TORCH_DT = {"fp32": torch.float32, "fp16": torch.float16}
+
+
+def interleave(a, dt):
+    a = np.ascontiguousarray(a.astype(np.complex64))
+    return torch.from_numpy(a.view(np.float32).reshape(a.shape + (2,))).to("cuda").to(dt).contiguous()
+
+
+def to_complex(t):
+    a = t.float().cpu().numpy().astype(np.float64)
+    return a[..., 0] + 1j * a[..., 1]
+
+
+def make_case(B, D, K, seed, real_input=False, real_filter=False):
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, D, N)) + (0 if real_input else 1j * rng.random((B, D, N)))
+    h = (rng.random((D, K)) + (0 if real_filter else 1j * rng.random((D, K)))) / N
+    return x.astype(np.complex128), h.astype(np.complex128)
+
+
+def run_conv(x, h, kind, dtype):
+    dt = TORCH_DT[dtype]
+    B, D, _ = x.shape
+    d_h = interleave(h, dt)
+    hp = conv.filter_spectra(d_h, N)
+    if kind == conv.CONV_COMPLEX:
+        d_x = interleave(x, dt)
+        x_stored = to_complex(d_x)
+    else:
+        d_x = torch.from_numpy(np.ascontiguousarray(x.real.astype(np.float32))).to("cuda").to(dt).contiguous()
+        x_stored = d_x.float().cpu().numpy().astype(np.float64) + 0j
+    y = conv.fft_conv(d_x, hp, N, kind)
+    torch.cuda.synchronize()
+    h_stored = to_complex(d_h)
+    if kind == conv.CONV_REAL_IN_OUT:
+        got = y.float().cpu().numpy().astype(np.float64) + 0j
+    else:
+        got = to_complex(y)
+    return got.reshape(B * D, N), x_stored.reshape(B * D, N), h_stored
+
+
+@pytest.mark.parametrize("K", [1, 9, 63, 257])
+def test_fp32_complex_vs_oracle(oracle_mod, K):
+    x, h = make_case(3, 5, K, seed=K)
+    got, xs, hs = run_conv(x, h, conv.CONV_COMPLEX, "fp32")
+    ref = oracle_mod.circular_conv(xs, hs) * N  # unnormalised inverse
+    err = oracle_mod.rel_l2(got, ref)
+    assert err <= 1e-5, f"K={K} rel_l2={err:.3e}"
+    assert err <= 3e-6, f"fp32 conv accuracy regressed: K={K} rel_l2={err:.3e}"
+
+
+@pytest.mark.parametrize("kind", [conv.CONV_COMPLEX, conv.CONV_REAL_IN, conv.CONV_REAL_IN_OUT])
+@pytest.mark.parametrize("K", [3, 33, 63])
+def test_fp16_vs_oracle(oracle_mod, kind, K):
+    real_in = kind != conv.CONV_COMPLEX
+    real_f = kind == conv.CONV_REAL_IN_OUT
+    x, h = make_case(4, 6, K, seed=100 + K + kind, real_input=real_in, real_filter=real_f)
+    got, xs, hs = run_conv(x, h, kind, "fp16")
+    ref = oracle_mod.circular_conv(xs, hs) * N
+    if kind == conv.CONV_REAL_IN_OUT:
+        ref = ref.real + 0j
+    err = oracle_mod.rel_l2(got, ref)
+    assert err <= 1e-2, f"kind={kind} K={K} rel_l2={err:.3e}"
+
+
+def test_signal_uses_filter_index_mod_D(oracle_mod):
+    # filter d is a delta at tap d scaled by (d + 1) / N: signal (b, d) comes back shifted by d and scaled
+    B, D = 3, 7
+    rng = np.random.default_rng(5)
+    x = (rng.random((B, D, N)) + 1j * rng.random((B, D, N))).astype(np.complex64)
+    h = np.zeros((D, D), dtype=np.complex64)
+    for d in range(D):
+        h[d, d] = (d + 1) / N
+    d_x = interleave(x, torch.float32)
+    y = to_complex(conv.fft_conv(d_x, conv.filter_spectra(interleave(h, torch.float32), N), N))
+    torch.cuda.synchronize()
+    for d in range(D):
+        want = np.roll(x[:, d].astype(np.complex128), d, axis=-1) * (d + 1)
+        assert np.linalg.norm(y[:, d] - want) / np.linalg.norm(want) < 3e-6, d
+
+
+def test_filter_layout_is_a_permutation():
+    D = 3
+    h = torch.arange(D * N * 2, dtype=torch.float32, device="cuda").reshape(D, N, 2).contiguous()
+    hp = conv.filter_layout(h, N)
+    torch.cuda.synchronize()
+    a = h.reshape(D, N, 2).cpu().numpy()
+    b = hp.reshape(D, N, 2).cpu().numpy()
+    for d in range(D):
+        # every (re, im) pair survives intact, and stays inside its own filter
+        assert np.array_equal(np.sort(a[d, :, 0]), np.sort(b[d, :, 0]))
+        assert np.array_equal(b[d, :, 1], b[d, :, 0] + 1)
+
+
+def test_large_batch_linearity_and_shift():
+    # full Figure-5 shape (B = 64, D = 768, real fp16 input, real filter): conv with a delta of weight
+    # 1/N returns the input; checked on every signal
+    B, D = 64, 768
+    x = torch.rand(B, D, N, device="cuda").to(torch.float16)
+    h = torch.zeros(D, 1, 2, device="cuda", dtype=torch.float16)
+    h[:, 0, 0] = 1.0 / N
+    hp = conv.filter_spectra(h, N)
+    y = conv.fft_conv(x, hp, N, conv.CONV_REAL_IN_OUT)
+    torch.cuda.synchronize()
+    err = (torch.linalg.vector_norm((y.float() - x.float())) / torch.linalg.vector_norm(x.float())).item()
+    assert err < 2e-3, err
+    yc = conv.fft_conv(x, hp, N, conv.CONV_REAL_IN)
+    torch.cuda.synchronize()
+    # two instantiations of the kernel: contraction order may differ by an fp16 ulp
+    assert torch.max(torch.abs(yc[..., 0].float() - y.float())).item() <= 1e-3
+    assert torch.max(torch.abs(yc[..., 1].float())).item() < 2e-3
+
+
+def test_errors():
+    x = torch.zeros(1, 1, 1024, 2, device="cuda")
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        conv.fft_conv(x, torch.zeros(1, 1024, 2, device="cuda"), 1024)
+    assert e.value.code == 1  # unsupported length
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        conv.fft_conv(torch.zeros(1, 2, N, device="cuda"), torch.zeros(2, N, 2, device="cuda"), N, conv.CONV_REAL_IN)
+    assert e.value.code == 1  # real input exists for fp16 storage only
+    with pytest.raises(fft_amd.ThunderFFTError):
+        conv.fft_conv(torch.zeros(1, 2, N, 2, device="cuda"), torch.zeros(3, N, 2, device="cuda"), N)

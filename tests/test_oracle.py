@@ -80,3 +80,20 @@ def test_roundtrip_and_linearity(oracle_mod):
     X, Y = oracle_mod.fft(x), oracle_mod.fft(y)
     assert oracle_mod.rel_l2(oracle_mod.fft(X, False) / n, x) < 1e-14
     assert oracle_mod.rel_l2(oracle_mod.fft(2.0 * x + 1j * y), 2.0 * X + 1j * Y) < 1e-14
+
+
+def test_circular_conv_definition_vs_transform(oracle_mod):
+    # the O(N K) definition (the reference's validation loop, conv1d_fullfft_l4096_thunder.cu:472-483)
+    # against the convolution theorem evaluated with the oracle's own transforms
+    rng = np.random.default_rng(3)
+    x = rng.random((7, 512)) + 1j * rng.random((7, 512))
+    h = rng.random((3, 17)) + 1j * rng.random((3, 17))
+    a = oracle_mod.circular_conv(x, h)
+    b = oracle_mod.circular_conv_fft(x, h)
+    assert oracle_mod.rel_l2(a, b) < 1e-13
+    # signal s uses filter s % D
+    assert np.allclose(a[4], oracle_mod.circular_conv(x[4:5], h[1:2])[0])
+    # a delta at tap k is a circular shift
+    d = np.zeros((1, 4), dtype=complex)
+    d[0, 3] = 2.0
+    assert np.allclose(oracle_mod.circular_conv(x[:1], d)[0], 2.0 * np.roll(x[0], 3))
