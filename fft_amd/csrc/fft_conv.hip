@@ -72,6 +72,80 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_kernel(const typename
   f.template store<IOOUT>(y + sig * (N / 2), 1, v);
 }
 
+// Real signals with a real filter, two signals (b, b+1) of one filter per workgroup: the pair
+// travels as one complex signal x_b + i x_{b+1}. Convolution with real taps is linear over the
+// reals, so the result is y_b + i y_{b+1}: half the butterflies, LDS traffic and filter reads per
+// signal. (A complex filter would mix the two; this kernel is only reached when the caller states
+// that the taps are real.)
+template <class P, class HIO>
+__global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_real_pair_kernel(const unsigned* __restrict__ x,
+                                                                            const typename HIO::raw* __restrict__ hp,
+                                                                            unsigned* __restrict__ y,
+                                                                            const float2* __restrict__ tw, int B, int D) {
+  static_assert(P::TPB == 1 && P::NB1 == 1 && P::NBL == 1, "one signal pair per workgroup, one butterfly per thread");
+  static_assert(BlockFFT<P>::kChainable, "first and last radix must agree");
+  using RIO = StoreRealF16;
+  constexpr int N = P::N, E = P::E, NRAW = P::NRAW, R1 = P::R1, RL = P::RL;
+  __shared__ __attribute__((aligned(16))) char lds[P::LDS_BYTES];
+
+  const int npair = (B + 1) >> 1;
+  const int d = blockIdx.x / npair;
+  const int b0 = 2 * (blockIdx.x - d * npair);
+  const bool two = b0 + 1 < B;
+  const long long s0 = (long long)b0 * D + d;
+  const long long s1 = s0 + D;
+
+  const BlockFFT<P> f(tw, lds);
+  unsigned pre0[NRAW], pre1[NRAW];
+  f.template load<RIO>(x + s0 * (N / 2), 1, pre0);
+  if (two) {
+    f.template load<RIO>(x + s1 * (N / 2), 1, pre1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) pre1[i] = 0u;
+  }
+  typename HIO::raw hraw[E / 2];
+  const typename HIO::raw* hsrc = hp + (long long)d * (N / 2) + f.tid;
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) hraw[j] = hsrc[j * P::WG];
+
+  c32 v[E];
+#pragma unroll
+  for (int i = 0; i < NRAW; ++i) {
+    c32 a0, a1, c0, c1;
+    RIO::unpack(pre0[i], a0, a1);
+    RIO::unpack(pre1[i], c0, c1);
+    v[i] = make_float2(a0.x, c0.x);
+    v[i + R1 / 2] = make_float2(a1.x, c1.x);
+    swap_points(v[i], v[i + R1 / 2]);
+  }
+  f.template transform<true>(v, false);
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) {
+    c32 h0, h1;
+    HIO::unpack(hraw[j], h0, h1);
+    v[2 * j] = cmul(v[2 * j], h0);
+    v[2 * j + 1] = cmul(v[2 * j + 1], h1);
+  }
+  f.template transform<false>(v, true);
+  unsigned* p0 = y + s0 * (N / 2) + f.st_base[0];
+  unsigned* p1 = y + s1 * (N / 2) + f.st_base[0];
+#pragma unroll
+  for (int i = 0; i < NRAW; ++i) {
+    c32 a = v[i], b = v[i + RL / 2];
+    swap_points(a, b);
+    RIO::store(p0 + i * (P::CL / 2), RIO::pack(make_float2(a.x, 0.f), make_float2(b.x, 0.f)));
+    if (two) RIO::store(p1 + i * (P::CL / 2), RIO::pack(make_float2(a.y, 0.f), make_float2(b.y, 0.f)));
+  }
+}
+
+template <class P, class HIO>
+void launch_conv_real_pair(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
+  const unsigned npair = ((unsigned)B + 1u) / 2u;
+  fft_conv_real_pair_kernel<P, HIO><<<dim3(npair * (unsigned)D), dim3(P::WG), 0, stream>>>(
+      static_cast<const unsigned*>(x), static_cast<const typename HIO::raw*>(hp), static_cast<unsigned*>(y), tw, B, D);
+}
+
 template <class P, class IOIN, class IOOUT, class HIO>
 void launch_conv(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
   fft_conv_kernel<P, IOIN, IOOUT, HIO><<<dim3((unsigned)B * (unsigned)D), dim3(P::WG), 0, stream>>>(
@@ -107,7 +181,10 @@ bool lookup_conv_plan(int dtype, int kind, ConvEntry* out) {
     switch (kind) {
       case kConvComplex: *out = make_conv_entry<P, StoreF16, StoreF16, StoreF16>(); return true;
       case kConvRealIn: *out = make_conv_entry<P, StoreRealF16, StoreF16, StoreF16>(); return true;
-      case kConvRealInOut: *out = make_conv_entry<P, StoreRealF16, StoreRealF16, StoreF16>(); return true;
+      case kConvRealInOut:
+        *out = make_conv_entry<P, StoreRealF16, StoreRealF16, StoreF16>();
+        out->launch = &launch_conv_real_pair<P, StoreF16>;
+        return true;
       default: return false;
     }
   }

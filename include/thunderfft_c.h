@@ -94,7 +94,8 @@ int tfft_fourstep_twiddle(int dtype, void* d_data, long long rows, long long col
  * contiguous and signal (b, d) uses filter d, i.e. filter = signal index % D (:171).
  *   kind TFFT_CONV_COMPLEX     : x and y interleaved complex of `dtype`
  *   kind TFFT_CONV_REAL_IN     : x real (n values per signal), y interleaved complex
- *   kind TFFT_CONV_REAL_IN_OUT : x real, y = real part of the result (exact for real filters)
+ *   kind TFFT_CONV_REAL_IN_OUT : x real, y real; the filter taps must be real (two signals then share
+ *                                one complex transform; complex taps give wrong results)
  * d_h_perm holds the D filter spectra in the kernel's register order, made by
  * tfft_conv_filter_layout. Supported: n = 4096; fp16 (all kinds), fp32 (complex kind).
  * Needs tfft_initialize(dtype, n). Asynchronous on `stream`; allocates nothing. */

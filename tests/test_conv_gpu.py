@@ -82,6 +82,19 @@ def test_fp16_vs_oracle(oracle_mod, kind, K):
     assert err <= 1e-2, f"kind={kind} K={K} rel_l2={err:.3e}"
 
 
+@pytest.mark.parametrize("B", [1, 5])
+def test_real_pairs_with_odd_batch(oracle_mod, B):
+    # real in / real out packs signals (b, b+1) into one complex transform; an odd B leaves one alone
+    x, h = make_case(B, 3, 17, seed=B, real_input=True, real_filter=True)
+    got, xs, hs = run_conv(x, h, conv.CONV_REAL_IN_OUT, "fp16")
+    ref = oracle_mod.circular_conv(xs, hs).real * N + 0j
+    err = oracle_mod.rel_l2(got, ref)
+    assert err <= 1e-2, f"B={B} rel_l2={err:.3e}"
+    # per signal too: a swapped or dropped pair member would hide in the aggregate
+    for s in range(got.shape[0]):
+        assert oracle_mod.rel_l2(got[s], ref[s]) <= 1e-2, s
+
+
 def test_signal_uses_filter_index_mod_D(oracle_mod):
     # filter d is a delta at tap d scaled by (d + 1) / N: signal (b, d) comes back shifted by d and scaled
     B, D = 3, 7
