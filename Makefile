@@ -18,7 +18,7 @@ KERNEL_HDRS := $(wildcard $(CSRC)/*.hpp) include/thunderfft_c.h
 LIB        := $(LIBDIR)/libthunderfft_hip.so
 ORACLE     := oracle/liboracle_dft.so
 BENCH      := bench/tfft_bench
-CONVBENCH  := bench/thff_conv1d_fullfft4096
+CONVBENCH  := bench/thff_conv1d_fullfft4096 bench/thff_conv1d
 
 .PHONY: all lib oracle bench clean
 all: lib oracle bench
@@ -41,8 +41,12 @@ $(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh 
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ bench/tfft_bench.cpp \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
-$(CONVBENCH): bench/thff_conv1d_fullfft4096.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
-	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ bench/thff_conv1d_fullfft4096.cpp \
+bench/thff_conv1d%: bench/thff_conv1d%.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
+	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+bench/thff_conv1d: bench/thff_conv1d.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 clean:

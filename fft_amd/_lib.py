@@ -16,6 +16,7 @@ SYMBOLS = (
     "tfft_fourstep_twiddle",
     "tfft_conv_exec",
     "tfft_conv_filter_layout",
+    "tfft_conv_tiles_exec",
     "tfft_last_error",
 )
 
@@ -59,6 +60,7 @@ def load():
     lib.tfft_fourstep_twiddle.argtypes = [i, vp, ll, ll, ll, ll, ll, i, vp]
     lib.tfft_conv_exec.argtypes = [i, i, i, vp, vp, vp, i, i, vp]
     lib.tfft_conv_filter_layout.argtypes = [i, i, vp, vp, i, vp]
+    lib.tfft_conv_tiles_exec.argtypes = [i, i, vp, vp, vp, ll, ll, i, vp]
     lib.tfft_last_error.argtypes = []
     lib.tfft_last_error.restype = cp
     for name in SYMBOLS:

@@ -65,3 +65,41 @@ def fft_conv(x, h_perm, N, kind=CONV_COMPLEX, out=None, stream=None):
         _check(_lib.load().tfft_conv_exec(dtype_code(x.dtype), int(N), int(kind), x.data_ptr(), h_perm.data_ptr(),
                                           out.data_ptr(), int(B), int(D), _stream(x, stream)))
     return out
+
+
+def tiled_filter_spectrum(taps, N=64):
+    """Filter taps [K, 2] -> the spectrum the tiled kernel multiplies by: taps stored at (N - i) % N and
+    scaled by 1/N (the reference's make_padded_filter_fft64, sample/conv1d/main.cu:145-154), transformed
+    in fp32 and rounded to the taps' element type (the reference: cuFFT fp32, then f32_to_half2, :280-287)."""
+    K = taps.shape[0]
+    if K > N:
+        raise ThunderFFTError(3, f"filter has {K} taps, tile transform length is {N}")
+    padded = torch.zeros(1, N, 2, dtype=torch.float32, device=taps.device)
+    idx = (N - torch.arange(K, device=taps.device)) % N
+    padded[0, idx] = taps.float() / N
+    ThunderFFTInitialize(torch.float32, N)
+    spec = torch.empty_like(padded)
+    ThunderFFT_global(padded, spec, 1, N, True)
+    return spec[0].to(taps.dtype).contiguous()
+
+
+def conv1d_tiled(x, hf, filter_len, N=64, out=None, stream=None):
+    """Valid cross-correlation out[i] = sum_k x[i + k] * filter[k] by overlap-save tiles of length N.
+
+    x: [L, 2] interleaved complex (float32 or float16) on the device; hf from tiled_filter_spectrum;
+    result [L - filter_len + 1, 2]. Mirrors the launch in sample/conv1d/main.cu:235-299."""
+    if not (x.is_cuda and x.is_contiguous()) or x.dim() != 2 or x.shape[1] != 2:
+        raise ThunderFFTError(3, "conv1d_tiled needs a contiguous device tensor [L, 2]")
+    L = x.shape[0]
+    if filter_len < 1 or filter_len > N or L < filter_len:
+        raise ThunderFFTError(3, f"need 1 <= filter_len <= {N} <= input length")
+    if hf.dtype != x.dtype or hf.numel() != 2 * N or not hf.is_contiguous():
+        raise ThunderFFTError(3, "filter spectrum must be contiguous [N, 2] of the signal's element type")
+    out_len = L - filter_len + 1
+    if out is None:
+        out = torch.empty(out_len, 2, dtype=x.dtype, device=x.device)
+    ThunderFFTInitialize(x.dtype, N)
+    with torch.cuda.device(x.device):
+        _check(_lib.load().tfft_conv_tiles_exec(dtype_code(x.dtype), int(N), x.data_ptr(), hf.data_ptr(), out.data_ptr(),
+                                                int(L), int(out_len), int(N - filter_len + 1), _stream(x, stream)))
+    return out

@@ -19,4 +19,12 @@ struct ConvEntry {
 
 bool lookup_conv(int dtype, int n, int kind, ConvEntry* out);
 
+// Overlap-save tiles of length n, `valid` outputs kept per tile.
+struct ConvTilesEntry {
+  void (*launch)(const void* in, const void* hf, void* out, const float2* tw, long long input_len, long long output_len,
+                 int valid, hipStream_t stream);
+  int n, threads, tiles_per_block;
+};
+bool lookup_conv_tiles(int dtype, int n, ConvTilesEntry* out);
+
 }  // namespace tfft

@@ -159,6 +159,79 @@ void launch_layout(const void* h, void* hp, int D, hipStream_t stream) {
       static_cast<const typename HIO::raw*>(h), static_cast<typename HIO::raw*>(hp), D);
 }
 
+// Overlap-save tiles: tile t transforms the n points in[t*valid .. t*valid + n) (zero past the end
+// of the input), multiplies by the filter spectrum hf (natural order, n points) and keeps the first
+// `valid` points of the inverse transform as out[t*valid .. t*valid + valid). TPB tiles per
+// workgroup. Replaces conv1d_direct_fft_kernel (thunderfft/sample/conv1d/main.cu:38-129), whose
+// tiles likewise start `valid_tile` apart and overlap by filter_len - 1 points. Tiles start at
+// arbitrary points, so global accesses are per point (4 or 8 bytes) rather than 16-byte pairs.
+template <class T>
+struct PointIO;
+template <>
+struct PointIO<float2> {
+  __device__ static __forceinline__ c32 get(const float2* p) { return *p; }
+  __device__ static __forceinline__ void put(float2* p, c32 v) { *p = v; }
+};
+template <>
+struct PointIO<__half2> {
+  __device__ static __forceinline__ c32 get(const __half2* p) { return __half22float2(*p); }
+  __device__ static __forceinline__ void put(__half2* p, c32 v) { *p = __float22half2_rn(v); }
+};
+
+template <class P, class T>
+__global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_tiles_kernel(const T* __restrict__ in, const T* __restrict__ hf,
+                                                                       T* __restrict__ out, const float2* __restrict__ tw,
+                                                                       long long input_len, long long output_len, int valid,
+                                                                       long long ntiles) {
+  static_assert(BlockFFT<P>::kChainable, "first and last radix must agree");
+  constexpr int E = P::E;
+  __shared__ __attribute__((aligned(16))) char lds[P::LDS_BYTES];
+  const BlockFFT<P> f(tw, lds);
+  const long long tile0 = (long long)blockIdx.x * P::TPB;
+
+  c32 v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const long long t = tile0 + f.transform_in(e);
+    const long long idx = t * valid + f.index_in(e);
+    v[e] = (t < ntiles && idx < input_len) ? PointIO<T>::get(in + idx) : make_float2(0.f, 0.f);
+  }
+  f.template transform<true>(v, false);
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = cmul(v[e], PointIO<T>::get(hf + f.index_out(e)));
+  f.template transform<false>(v, true);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const long long t = tile0 + f.transform_out(e);
+    const int j = f.index_out(e);
+    const long long idx = t * valid + j;
+    if (t < ntiles && j < valid && idx < output_len) PointIO<T>::put(out + idx, v[e]);
+  }
+}
+
+template <class P, class T>
+void launch_conv_tiles(const void* in, const void* hf, void* out, const float2* tw, long long input_len,
+                       long long output_len, int valid, hipStream_t stream) {
+  const long long ntiles = (output_len + valid - 1) / valid;
+  const long long blocks = (ntiles + P::TPB - 1) / P::TPB;
+  fft_conv_tiles_kernel<P, T><<<dim3((unsigned)blocks), dim3(P::WG), 0, stream>>>(
+      static_cast<const T*>(in), static_cast<const T*>(hf), static_cast<T*>(out), tw, input_len, output_len, valid, ntiles);
+}
+
+// 4 x 4 x 4 with 16 points per thread: 4 threads per tile, 16 tiles per 64-thread workgroup
+using ConvTilePlan64 = Plan<64, 16, 4, 4, 4, 64, 5, 4, 5, 1>;
+
+bool lookup_conv_tiles(int dtype, int n, ConvTilesEntry* out) {
+  if (n != 64) return false;
+  using P = ConvTilePlan64;
+  out->n = P::N;
+  out->threads = P::WG;
+  out->tiles_per_block = P::TPB;
+  if (dtype == TFFT_F32) { out->launch = &launch_conv_tiles<P, float2>; return true; }
+  if (dtype == TFFT_F16) { out->launch = &launch_conv_tiles<P, __half2>; return true; }
+  return false;
+}
+
 template <class P, class IOIN, class IOOUT, class HIO>
 ConvEntry make_conv_entry() {
   ConvEntry e;

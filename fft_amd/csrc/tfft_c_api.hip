@@ -482,4 +482,33 @@ int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_
   return TFFT_OK;
 }
 
+int tfft_conv_tiles_exec(int dtype, int n, const void* d_in, const void* d_hf, void* d_out, long long input_len,
+                         long long output_len, int valid, void* stream) {
+  tfft::ConvTilesEntry e;
+  if (!tfft::lookup_conv_tiles(dtype, n, &e))
+    return fail(TFFT_ERR_UNSUPPORTED, "tfft_conv_tiles_exec: no tiled convolution kernel for %s n=%d", dtype_name(dtype), n);
+  if (input_len < 0 || output_len < 0 || valid < 1 || valid > n)
+    return fail(TFFT_ERR_INVALID, "tfft_conv_tiles_exec: need 1 <= valid <= n and non-negative lengths");
+  if (output_len == 0) return TFFT_OK;
+  if (!d_in || !d_hf || !d_out) return fail(TFFT_ERR_INVALID, "tfft_conv_tiles_exec: null device pointer");
+  const long long ntiles = (output_len + valid - 1) / valid;
+  if ((ntiles + e.tiles_per_block - 1) / e.tiles_per_block > 0x7fffffffLL)
+    return fail(TFFT_ERR_INVALID, "tfft_conv_tiles_exec: too many tiles for one launch");
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  DevicePlan plan;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+    if (it == g_plans.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_tiles_exec: call tfft_initialize(%s, %d) on device %d first",
+                  dtype_name(dtype), n, dev);
+    plan = it->second;
+  }
+  e.launch(d_in, d_hf, d_out, plan.tw, input_len, output_len, valid, static_cast<hipStream_t>(stream));
+  TFFT_HIP(hipGetLastError());
+  if (g_opt.sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return TFFT_OK;
+}
+
 }  // extern "C"

@@ -109,6 +109,18 @@ int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_
  * alias d_h_freq. */
 int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream);
 
+/* Overlap-save tiled convolution with transforms of length n: for every tile t,
+ *   out[t*valid + j] = IDFT_n( DFT_n(in[t*valid .. t*valid + n)) * hf )[j],   j < valid, t*valid + j < output_len,
+ * input points at or past input_len read as zero, unnormalised. Replaces conv1d_direct_fft_kernel
+ * and its launch (sample/conv1d/main.cu:38-129, 294-299), where valid = n - filter_len + 1,
+ * output_len = input_len - filter_len + 1 and hf is the spectrum of the taps stored at
+ * (n - i) % n and scaled by 1/n (:145-154), which makes the result the valid cross-correlation
+ * sum_k in[i + k] * filter[k] (:156-174). in, out: interleaved complex of `dtype` (fp32 or fp16);
+ * hf: n points of the same type, natural order. n = 64. Needs tfft_initialize(dtype, n).
+ * Asynchronous on `stream`; allocates nothing. in and out must not overlap. */
+int tfft_conv_tiles_exec(int dtype, int n, const void* d_in, const void* d_hf, void* d_out, long long input_len,
+                         long long output_len, int valid, void* stream);
+
 const char* tfft_last_error(void);
 
 #ifdef __cplusplus

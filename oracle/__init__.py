@@ -11,6 +11,7 @@ from .fft_oracle import (  # noqa: F401
     fft,
     circular_conv,
     circular_conv_fft,
+    valid_correlation,
     rel_l2,
     max_abs_err,
 )

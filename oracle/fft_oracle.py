@@ -108,6 +108,18 @@ def circular_conv_fft(x, h):
     return fft_radix2(X * H[np.arange(signals) % D], False) / n
 
 
+def valid_correlation(x, taps):
+    """out[i] = sum_k x[i + k] * taps[k], i < len(x) - len(taps) + 1, no conjugation: the reference's
+    reference_conv1d_valid (thunderfft/sample/conv1d/main.cu:156-174) in fp64."""
+    x = np.asarray(x).astype(np.complex128)
+    taps = np.asarray(taps).astype(np.complex128)
+    n_out = x.shape[0] - taps.shape[0] + 1
+    out = np.zeros(n_out, dtype=np.complex128)
+    for k in range(taps.shape[0]):
+        out += x[k:k + n_out] * taps[k]
+    return out
+
+
 def rel_l2(test, ref):
     """Relative L2 error over the whole batch, the reference's l2_rel
     (thunderfft/sample/fft1d/main.cu:48-58) in fp64."""

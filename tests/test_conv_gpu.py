@@ -153,3 +153,33 @@ def test_errors():
     assert e.value.code == 1  # real input exists for fp16 storage only
     with pytest.raises(fft_amd.ThunderFFTError):
         conv.fft_conv(torch.zeros(1, 2, N, 2, device="cuda"), torch.zeros(3, N, 2, device="cuda"), N)
+
+
+# ---- overlap-save tiles of length 64 (tfft_conv_tiles_exec)
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("fp16", 1e-2)])
+@pytest.mark.parametrize("L,K", [(65536, 9), (5000, 1), (5000, 33), (777, 64), (64, 64), (100, 37)])
+def test_tiled_conv_vs_oracle(oracle_mod, dtype, tol, L, K):
+    rng = np.random.default_rng(L + K)
+    x = (rng.random(L) + 1j * rng.random(L)).astype(np.complex64)
+    taps = (rng.random(K) + 1j * rng.random(K)).astype(np.complex64)
+    dt = TORCH_DT[dtype]
+    d_x = interleave(x, dt)
+    d_t = interleave(taps, dt)
+    hf = conv.tiled_filter_spectrum(d_t, 64)
+    y = conv.conv1d_tiled(d_x, hf, K, 64)
+    torch.cuda.synchronize()
+    assert y.shape == (L - K + 1, 2)
+    ref = oracle_mod.valid_correlation(to_complex(d_x), to_complex(d_t))
+    err = oracle_mod.rel_l2(to_complex(y), ref)
+    assert err <= tol, f"L={L} K={K} rel_l2={err:.3e}"
+
+
+def test_tiled_conv_does_not_write_past_output():
+    L, K = 1000, 9
+    x = torch.rand(L, 2, device="cuda")
+    hf = conv.tiled_filter_spectrum(torch.rand(K, 2, device="cuda"), 64)
+    buf = torch.full((L + 64, 2), -7.0, device="cuda")
+    conv.conv1d_tiled(x, hf, K, 64, out=buf[: L - K + 1])
+    torch.cuda.synchronize()
+    assert torch.all(buf[L - K + 1:] == -7.0)
+    assert torch.all(buf[: L - K + 1] != -7.0)

@@ -97,3 +97,16 @@ def test_circular_conv_definition_vs_transform(oracle_mod):
     d = np.zeros((1, 4), dtype=complex)
     d[0, 3] = 2.0
     assert np.allclose(oracle_mod.circular_conv(x[:1], d)[0], 2.0 * np.roll(x[0], 3))
+
+
+def test_valid_correlation_is_a_slice_of_circular_conv(oracle_mod):
+    # sum_k x[i + k] f[k] (sample/conv1d/main.cu:156-174) equals the circular convolution of x with the
+    # taps stored at (N - k) % N (:145-154) wherever no index wraps
+    rng = np.random.default_rng(9)
+    n, K = 64, 9
+    x = rng.random(n) + 1j * rng.random(n)
+    f = rng.random(K) + 1j * rng.random(K)
+    padded = np.zeros((1, n), dtype=complex)
+    padded[0, (n - np.arange(K)) % n] = f
+    circ = oracle_mod.circular_conv(x[None, :], padded)[0]
+    assert np.allclose(oracle_mod.valid_correlation(x, f), circ[: n - K + 1])
