@@ -20,8 +20,9 @@ ORACLE     := oracle/liboracle_dft.so
 BENCH      := bench/tfft_bench
 CONVBENCH  := bench/thff_conv1d_fullfft4096 bench/thff_conv1d
 
-.PHONY: all lib oracle bench clean
-all: lib oracle bench
+.PHONY: all lib oracle bench examples clean
+all: lib oracle bench examples
+examples: examples/libspectral_mask.so
 lib: $(LIB)
 oracle: $(ORACLE)
 bench: $(BENCH) $(CONVBENCH)
@@ -49,5 +50,9 @@ bench/thff_conv1d: bench/thff_conv1d.cpp include/thunderfft/thunderfft.cuh inclu
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
+# user kernel built on the device-level API (include/thunderfft/thunderfft_device.hpp)
+examples/libspectral_mask.so: examples/spectral_mask.hip include/thunderfft/thunderfft_device.hpp $(KERNEL_HDRS) $(LIB)
+	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $< -L$(LIBDIR) -lthunderfft_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
 clean:
-	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH) $(CONVBENCH)
+	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH) $(CONVBENCH) examples/libspectral_mask.so

@@ -17,6 +17,7 @@ SYMBOLS = (
     "tfft_conv_exec",
     "tfft_conv_filter_layout",
     "tfft_conv_tiles_exec",
+    "tfft_get_twiddle_table",
     "tfft_last_error",
 )
 
@@ -61,6 +62,7 @@ def load():
     lib.tfft_conv_exec.argtypes = [i, i, i, vp, vp, vp, i, i, vp]
     lib.tfft_conv_filter_layout.argtypes = [i, i, vp, vp, i, vp]
     lib.tfft_conv_tiles_exec.argtypes = [i, i, vp, vp, vp, ll, ll, i, vp]
+    lib.tfft_get_twiddle_table.argtypes = [i, i, ctypes.POINTER(vp)]
     lib.tfft_last_error.argtypes = []
     lib.tfft_last_error.restype = cp
     for name in SYMBOLS:

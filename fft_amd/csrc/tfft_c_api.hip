@@ -306,6 +306,19 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info) {
   return TFFT_OK;
 }
 
+int tfft_get_twiddle_table(int dtype, int n, const void** d_table) {
+  if (!d_table) return fail(TFFT_ERR_INVALID, "tfft_get_twiddle_table: null result pointer");
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+  if (it == g_plans.end())
+    return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_get_twiddle_table: call tfft_initialize(%s, %d) on device %d first",
+                dtype_name(dtype), n, dev);
+  *d_table = it->second.tw;
+  return TFFT_OK;
+}
+
 int tfft_set_option(const char* key, long long value) {
   if (!key) return fail(TFFT_ERR_INVALID, "tfft_set_option: null key");
   std::lock_guard<std::mutex> lock(g_mu);

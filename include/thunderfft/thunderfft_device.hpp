@@ -1,0 +1,116 @@
+// ThunderFFT device-level API for MI355X (gfx950): the pieces of the batched kernel as device
+// functions, so that a user kernel can put its own work between a forward and an inverse transform
+// without a round trip through HBM.
+//
+// Counterpart of the reference's composable device pipeline (thunderfft/include/thunderfft/
+// thunderfft.cuh:55-130):
+//     ThunderFFT_gmem2smem -> ThunderFFT_smem2reg -> ThunderFFT_kernel_reg -> ThunderFFT_reg2smem ->
+//     ThunderFFT_smem2gmem      (and the direct ThunderFFT_gmem2reg / ThunderFFT_reg2gmem, :55-65)
+// The reference stages rows through shared memory into mma.m16n8k8 fragments. On wave64 hardware a
+// thread's points go from global memory straight into VGPRs in the order its first butterfly pass
+// wants them, so the shared-memory staging calls have no counterpart: the three calls below are
+// the whole pipeline, and LDS is only the transform's internal exchange buffer (`workspace`).
+//
+//   template <int N> __global__ __launch_bounds__(thunderfft::block_threads<N>)
+//   void my_kernel(const float2* in, float2* out, const float2* tw, int batch) {
+//     __shared__ __attribute__((aligned(16))) char workspace[thunderfft::workspace_bytes<N>];
+//     thunderfft::DeviceFFT<N> fft(tw, workspace);
+//     float2 reg[thunderfft::elements_per_thread<N>];
+//     const long long first = (long long)blockIdx.x * thunderfft::batch_per_block<N>;
+//     const int valid = min((long long)thunderfft::batch_per_block<N>, batch - first);
+//     thunderfft::ThunderFFT_gmem2reg<float, N>(fft, reg, in + first * N, valid);
+//     thunderfft::ThunderFFT_kernel_reg<N, true>(fft, reg, /*lead=*/false);
+//     for (int e = 0; e < thunderfft::elements_per_thread<N>; ++e)   // reg[e] is bin fft.index_out(e)
+//       reg[e] = my_filter(reg[e], fft.index_out(e));                //   of transform fft.transform_out(e)
+//     thunderfft::ThunderFFT_kernel_reg<N, false>(fft, reg);
+//     thunderfft::ThunderFFT_reg2gmem<float, N>(fft, out + first * N, reg, valid);
+//   }
+//
+// `tw` is the table tfft_initialize built; tfft_get_twiddle_table returns its device address.
+// Chaining a forward and an inverse transform in registers needs thunderfft::is_chainable<N>
+// (the register order after a transform equals the order the next one expects): N = 64, 128, 256,
+// 1024, 4096. Compile user kernels with hipcc --offload-arch=gfx950 -fno-slp-vectorize and
+// -I<repo>/include; this header pulls the kernel sources from <repo>/fft_amd/csrc.
+#pragma once
+#include "thunderfft.cuh"
+
+#include "../../fft_amd/csrc/fft_block.hpp"
+#include "../../fft_amd/csrc/plans.hpp"
+
+namespace thunderfft {
+
+template <int N>
+struct device_plan;
+template <> struct device_plan<64> { using type = tfft::Plan64; };
+template <> struct device_plan<128> { using type = tfft::Plan128; };
+template <> struct device_plan<256> { using type = tfft::Plan256; };
+template <> struct device_plan<512> { using type = tfft::Plan512; };
+template <> struct device_plan<1024> { using type = tfft::Plan1024; };
+template <> struct device_plan<2048> { using type = tfft::Plan2048; };
+template <> struct device_plan<4096> { using type = tfft::Plan4096; };
+template <> struct device_plan<8192> { using type = tfft::Plan8192; };
+template <> struct device_plan<16384> { using type = tfft::Plan16384; };
+
+template <typename T>
+struct device_io;
+template <> struct device_io<float> { using type = tfft::StoreF32; };
+template <> struct device_io<__half> { using type = tfft::StoreF16; };
+template <> struct device_io<__hip_bfloat16> { using type = tfft::StoreBF16; };
+
+// One workgroup's transform state: per-thread index maps, twiddle bases, the LDS workspace.
+template <int N>
+using DeviceFFT = tfft::BlockFFT<typename device_plan<N>::type>;
+
+// Launch geometry of a user kernel (reference: threads_per_warp * warp_per_block<N>,
+// batch_per_block<N>, the `ept` of its samples and the shared-memory size,
+// detail/thunderfft_impl.cuh:14-32, sample/conv1d/conv1d_fullfft_l4096_thunder.cu:25-27, 394).
+template <int N> inline constexpr int block_threads = device_plan<N>::type::WG;
+template <int N> inline constexpr int batch_per_block = device_plan<N>::type::TPB;
+template <int N> inline constexpr int elements_per_thread = device_plan<N>::type::E;
+template <int N> inline constexpr int workspace_bytes = device_plan<N>::type::LDS_BYTES;
+template <int N> inline constexpr bool is_chainable = DeviceFFT<N>::kChainable;
+
+// Global memory -> register file (reference: ThunderFFT_gmem2reg, thunderfft.cuh:55-58). `gmem`
+// addresses this workgroup's batch_per_block<N> transforms ([batch][N], 16-byte aligned); transforms
+// numbered `valid` and above read as zero. reg[e] becomes point fft.index_in(e) of transform
+// fft.transform_in(e), widened to fp32.
+template <typename T, int N>
+__device__ __forceinline__ void ThunderFFT_gmem2reg(const DeviceFFT<N>& fft, float2 (&reg)[elements_per_thread<N>],
+                                                    const vec2_t<T>* __restrict__ gmem,
+                                                    int valid = batch_per_block<N>) {
+  using IO = typename device_io<T>::type;
+  typename IO::raw raw[elements_per_thread<N> / 2];
+  fft.template load<IO>(reinterpret_cast<const typename IO::raw*>(gmem), valid, raw);
+  fft.template unpack<IO>(raw, reg);
+}
+
+// Register file -> global memory (reference: ThunderFFT_reg2gmem, thunderfft.cuh:61-65): reg[e] is
+// stored as point fft.index_out(e) of transform fft.transform_out(e), rounded to T.
+template <typename T, int N>
+__device__ __forceinline__ void ThunderFFT_reg2gmem(const DeviceFFT<N>& fft, vec2_t<T>* __restrict__ gmem,
+                                                    const float2 (&reg)[elements_per_thread<N>],
+                                                    int valid = batch_per_block<N>) {
+  using IO = typename device_io<T>::type;
+  fft.template store<IO>(reinterpret_cast<typename IO::raw*>(gmem), valid, reg);
+}
+
+// Register-resident transform (reference: ThunderFFT_kernel_reg<T, N, batch, forward>(reg, W,
+// workspace), thunderfft.cuh:127-130; W and workspace were given to the DeviceFFT constructor).
+// Unnormalised in both directions. `lead`: the workspace may still be read by an earlier
+// ThunderFFT_kernel_reg call or by user code, so begin with a barrier; pass false for the first use
+// in a kernel.
+template <int N, bool forward>
+__device__ __forceinline__ void ThunderFFT_kernel_reg(const DeviceFFT<N>& fft, float2 (&reg)[elements_per_thread<N>],
+                                                      bool lead = true) {
+  fft.template transform<forward>(reg, lead);
+}
+
+// Device address of the table ThunderFFTInitialize<T>(N) built on the current device.
+template <typename T>
+inline const float2* twiddle_table(int N) {
+  const void* p = nullptr;
+  check(tfft_get_twiddle_table(dtype_code<T>(), N, &p), "twiddle_table");
+  return static_cast<const float2*>(p);
+}
+
+}  // namespace thunderfft

@@ -121,6 +121,13 @@ int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_pe
 int tfft_conv_tiles_exec(int dtype, int n, const void* d_in, const void* d_hf, void* d_out, long long input_len,
                          long long output_len, int valid, void* stream);
 
+/* Device address of the twiddle table tfft_initialize(dtype, n) built on the current device:
+ * n float2 entries W_n^k = (cos, -sin)(2 pi k / n). For user kernels built on the device-level API
+ * (include/thunderfft/thunderfft_device.hpp), which take the table as an argument the way the
+ * reference's ThunderFFT_kernel_reg takes W (thunderfft.cuh:127-130). n <= 16384. The table stays
+ * valid until tfft_finalize(dtype). */
+int tfft_get_twiddle_table(int dtype, int n, const void** d_table);
+
 const char* tfft_last_error(void);
 
 #ifdef __cplusplus

@@ -19,8 +19,9 @@ def pytest_sessionstart(session):
 
     lib = os.path.join(ROOT, "fft_amd", "lib", "libthunderfft_hip.so")
     ora = os.path.join(ROOT, "oracle", "liboracle_dft.so")
-    if not (os.path.exists(lib) and os.path.exists(ora)):
-        subprocess.check_call(["make", "-C", ROOT, "-j8", "lib", "oracle"], stdout=subprocess.DEVNULL)
+    ex = os.path.join(ROOT, "examples", "libspectral_mask.so")
+    if not (os.path.exists(lib) and os.path.exists(ora) and os.path.exists(ex)):
+        subprocess.check_call(["make", "-C", ROOT, "-j8", "lib", "oracle", "examples"], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
