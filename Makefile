@@ -38,8 +38,8 @@ $(LIB): $(KERNEL_OBJS)
 $(ORACLE): oracle/dft_oracle.c
 	$(CC) -O2 -fPIC -shared -o $@ $< -lm
 
-$(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh $(LIB)
-	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ bench/tfft_bench.cpp \
+$(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh include/thunderfft/thunderfft_device.hpp $(KERNEL_HDRS) $(LIB)
+	$(HIPCC) -O3 -std=c++17 -fno-slp-vectorize --offload-arch=$(ARCH) -Iinclude -o $@ bench/tfft_bench.cpp \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 bench/thff_conv1d%: bench/thff_conv1d%.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)

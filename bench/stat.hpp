@@ -14,6 +14,7 @@ struct RunStat {
   std::string radix;   // e.g. "16x16x16"
   long long B;
   double max_abs_err;  // vs the hipFFT comparator, like the reference's vs-cuFFT figure
+  double compute_ms;   // (t(2R) - t(R)) / R in-kernel repeats: one transform pass without HBM; NaN if not run
   double e2e_ms;       // mean of the timed single launches
   double gflops;       // 5 N log2 N per transform
   double gbps;         // one read + one write of every point
@@ -33,25 +34,26 @@ inline void push(const RunStat& s) { rows().push_back(s); }
 
 inline void print_table() {
   std::printf("\n== %s ==\n", title().c_str());
-  std::printf("%-20s %7s %10s %9s %12s %10s %11s %9s %7s\n", "type", "N", "radix", "batch", "max_abs_err",
-              "e2e_ms", "GFLOP/s", "GB/s", "%HBM");
+  std::printf("%-20s %7s %10s %9s %12s %10s %10s %11s %9s %7s\n", "type", "N", "radix", "batch", "max_abs_err",
+              "compute_ms", "e2e_ms", "GFLOP/s", "GB/s", "%HBM");
   for (const auto& s : rows())
-    std::printf("%-20s %7u %10s %9lld %12.3e %10.4f %11.1f %9.1f %6.1f%%\n", s.type.c_str(), s.N, s.radix.c_str(),
-                s.B, s.max_abs_err, s.e2e_ms, s.gflops, s.gbps, 100.0 * s.hbm_frac);
+    std::printf("%-20s %7u %10s %9lld %12.3e %10.4f %10.4f %11.1f %9.1f %6.1f%%\n", s.type.c_str(), s.N,
+                s.radix.c_str(), s.B, s.max_abs_err, s.compute_ms, s.e2e_ms, s.gflops, s.gbps, 100.0 * s.hbm_frac);
 }
 
 inline void print_csv() {
-  std::printf("type,N,radix,B,max_abs_err,e2e_ms,gflops,gbps,hbm_frac\n");
+  std::printf("type,N,radix,B,max_abs_err,compute_ms,e2e_ms,gflops,gbps,hbm_frac\n");
   for (const auto& s : rows())
-    std::printf("%s,%u,%s,%lld,%.6e,%.6f,%.3f,%.3f,%.5f\n", s.type.c_str(), s.N, s.radix.c_str(), s.B, s.max_abs_err,
-                s.e2e_ms, s.gflops, s.gbps, s.hbm_frac);
+    std::printf("%s,%u,%s,%lld,%.6e,%.6f,%.6f,%.3f,%.3f,%.5f\n", s.type.c_str(), s.N, s.radix.c_str(), s.B, s.max_abs_err,
+                s.compute_ms, s.e2e_ms, s.gflops, s.gbps, s.hbm_frac);
 }
 
 inline void print_ndjson() {
   for (const auto& s : rows())
-    std::printf("{\"type\":\"%s\",\"N\":%u,\"radix\":\"%s\",\"B\":%lld,\"max_abs_err\":%.6e,\"e2e_ms\":%.6f,"
+    std::printf("{\"type\":\"%s\",\"N\":%u,\"radix\":\"%s\",\"B\":%lld,\"max_abs_err\":%.6e,\"compute_ms\":%.6f,\"e2e_ms\":%.6f,"
                 "\"gflops\":%.3f,\"gbps\":%.3f,\"hbm_frac\":%.5f}\n",
-                s.type.c_str(), s.N, s.radix.c_str(), s.B, s.max_abs_err, s.e2e_ms, s.gflops, s.gbps, s.hbm_frac);
+                s.type.c_str(), s.N, s.radix.c_str(), s.B, s.max_abs_err, s.compute_ms, s.e2e_ms, s.gflops, s.gbps,
+                s.hbm_frac);
 }
 
 }  // namespace stat

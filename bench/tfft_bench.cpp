@@ -5,9 +5,14 @@
 // events: one warm-up, the mean of `runs` launches. On top of the reference's milliseconds it
 // reports GFLOP/s (5 N log2 N), GB/s (one read + one write per point) and the fraction of 8 TB/s.
 //
+// compute_ms is the reference's second figure (util/helper.h:122-141, baseline/thunderfft_bench.h:7-55):
+// a kernel that loads once, runs the register-resident transform R times and stores once is timed
+// at R and 2R in-kernel repeats, compute_ms = (t(2R) - t(R)) / R -- the cost of one transform pass
+// over the batch with HBM taken out. Built on the device-level API; fp32 storage only.
+//
 // Usage: tfft_bench [--n 256,4096] [--points 268435456] [--runs 10] [--input sine|hash]
 //                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--extra-lds BYTES] [--csv] [--ndjson]
-//                   [--no-hipfft]
+//                   [--no-hipfft] [--inside-repeats R]   (R = 0 skips compute_ms)
 #include <hipfft/hipfft.h>
 
 #include <cmath>
@@ -17,7 +22,7 @@
 #include <vector>
 
 #define THUNDERFFT_ASYNC
-#include <thunderfft/thunderfft.cuh>
+#include <thunderfft/thunderfft_device.hpp>
 
 #include "stat.hpp"
 
@@ -43,6 +48,54 @@ __global__ __launch_bounds__(256) void reference_copy(const copy_f32x4* in, copy
   __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// The reference's ThunderFFT_benchmark_reg (baseline/thunderfft_bench.h:7-55): values overflow after a
+// few unnormalised passes, which does not change the instruction timing.
+template <int N>
+__global__ __launch_bounds__(thunderfft::block_threads<N>) void benchmark_reg_kernel(const float2* __restrict__ in,
+                                                                                      float2* __restrict__ out,
+                                                                                      const float2* __restrict__ tw,
+                                                                                      long long batch, unsigned inside_repeats) {
+  constexpr int BPB = thunderfft::batch_per_block<N>;
+  __shared__ __attribute__((aligned(16))) char workspace[thunderfft::workspace_bytes<N>];
+  thunderfft::DeviceFFT<N> fft(tw, workspace);
+  const long long first = (long long)blockIdx.x * BPB;
+  const int valid = (int)((batch - first < BPB) ? batch - first : BPB);
+  float2 reg[thunderfft::elements_per_thread<N>];
+  thunderfft::ThunderFFT_gmem2reg<float, N>(fft, reg, in + first * N, valid);
+#pragma unroll 1
+  for (unsigned i = 0; i < inside_repeats; ++i) thunderfft::ThunderFFT_kernel_reg<N, true>(fft, reg, true);
+  // the result is not meaningful after repeated passes: dump the registers in thread order (one
+  // coalesced 8-byte store per register) instead of the transform's natural-order store
+  if (valid == BPB) {
+#pragma unroll
+    for (int e = 0; e < thunderfft::elements_per_thread<N>; ++e)
+      out[first * N + (long long)e * thunderfft::block_threads<N> + threadIdx.x] = reg[e];
+  }
+}
+
+template <int N>
+void launch_benchmark_reg(float2* data, long long batch, unsigned repeats, hipStream_t s) {
+  constexpr int BPB = thunderfft::batch_per_block<N>;
+  const float2* tw = thunderfft::twiddle_table<float>(N);
+  benchmark_reg_kernel<N><<<dim3((unsigned)((batch + BPB - 1) / BPB)), dim3(thunderfft::block_threads<N>), 0, s>>>(
+      data, data, tw, batch, repeats);
+}
+
+bool launch_benchmark_reg_n(int n, float2* data, long long batch, unsigned repeats, hipStream_t s) {
+  switch (n) {
+    case 64: launch_benchmark_reg<64>(data, batch, repeats, s); return true;
+    case 128: launch_benchmark_reg<128>(data, batch, repeats, s); return true;
+    case 256: launch_benchmark_reg<256>(data, batch, repeats, s); return true;
+    case 512: launch_benchmark_reg<512>(data, batch, repeats, s); return true;
+    case 1024: launch_benchmark_reg<1024>(data, batch, repeats, s); return true;
+    case 2048: launch_benchmark_reg<2048>(data, batch, repeats, s); return true;
+    case 4096: launch_benchmark_reg<4096>(data, batch, repeats, s); return true;
+    case 8192: launch_benchmark_reg<8192>(data, batch, repeats, s); return true;
+    case 16384: launch_benchmark_reg<16384>(data, batch, repeats, s); return true;
+    default: return false;
+  }
+}
+
 struct Args {
   std::vector<int> ns = {256, 512, 1024, 2048, 4096, 8192, 16384};
   long long points = 1ll << 28;
@@ -55,6 +108,7 @@ struct Args {
   int extra_lds = 0;
   long long skew = 0;  // bytes added to the output buffer's address (out of place only)
   bool csv = false, ndjson = false, hipfft = true;
+  int inside_repeats = 0;
 };
 
 float time_ms(hipStream_t s, int warm, int runs, const std::function<void()>& fn) {
@@ -87,10 +141,10 @@ double max_abs_err(const float2* ref, const float2* test, size_t n) {
 }
 
 void push_row(const std::string& type, int n, const std::string& radix, long long batch, double err, double ms,
-              double bytes_per_point) {
+              double bytes_per_point, double compute_ms = NAN) {
   const double flops = 5.0 * n * std::log2((double)n) * batch;
   const double bytes = bytes_per_point * (double)n * batch;
-  stat::push({type, (unsigned)n, radix, batch, err, ms, flops / ms * 1e-6, bytes / ms * 1e-6,
+  stat::push({type, (unsigned)n, radix, batch, err, compute_ms, ms, flops / ms * 1e-6, bytes / ms * 1e-6,
               bytes / ms * 1e-6 / 8000.0});
 }
 
@@ -213,9 +267,20 @@ void run_one(const Args& a, int n) {
   tfft_set_option("mode", 0);
   tfft_set_option("extra_lds", 0);
 
+  double compute_ms = NAN;
+  if constexpr (std::is_same_v<T, float>) {
+    if (a.inside_repeats > 0 && n <= 16384) {
+      const unsigned R = (unsigned)a.inside_repeats;
+      float2* buf = reinterpret_cast<float2*>(d_perf);
+      const float t_r = time_ms(s, 1, 1, [&] { launch_benchmark_reg_n(n, buf, batch, R, s); });
+      const float t_2r = time_ms(s, 1, 1, [&] { launch_benchmark_reg_n(n, buf, batch, 2 * R, s); });
+      compute_ms = ((double)t_2r - (double)t_r) / (double)R;
+    }
+  }
+
   const double bpp = 2.0 * sizeof(vec2_t<T>);
   push_row(std::string("thunderfft(") + a.dtype + (a.mode ? ",mode" + std::to_string(a.mode) : "") + ")", n, radix.str(),
-           batch, err, ms, bpp);
+           batch, err, ms, bpp, compute_ms);
   if (hipfft_ms > 0) push_row("hipfft(fp32)", n, "-", batch, 0.0, hipfft_ms, 16.0);
   {
     const size_t bytes = sizeof(vec2_t<T>) * total;
@@ -257,6 +322,7 @@ int main(int argc, char** argv) {
     else if (k == "--csv") a.csv = true;
     else if (k == "--ndjson") a.ndjson = true;
     else if (k == "--no-hipfft") a.hipfft = false;
+    else if (k == "--inside-repeats") a.inside_repeats = std::stoi(val());
     else { std::fprintf(stderr, "unknown argument %s\n", k.c_str()); return 2; }
   }
   CHECK_HIP(hipSetDevice(0));

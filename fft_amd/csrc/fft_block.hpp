@@ -78,80 +78,57 @@ struct BlockFFT {
   static constexpr bool kChainable = (R1 == RL);  // index_out == index_in: transforms can be chained in registers
   static_assert(!P::MFMA_MID && !P::PREFETCH, "BlockFFT covers the plain VALU plans");
 
+  // State is the thread id, the table and the workspace only: every index map below is a pure
+  // function of the thread id (shifts and masks, all sizes being powers of two), recomputed where
+  // it is used and folded by common-subexpression elimination. (Member arrays of butterfly indices
+  // defeat scalar replacement once several members are used in one kernel and end up in scratch.)
   int tid, hi;
-  int b1_tr[NB1], b1_c[NB1], ld_base[NG1], ld_tr[NG1];
-  int bl_tr[NBL], bl_q[NBL], st_base[NGL], st_tr[NGL];
-  int b2_tr[NB2], b2_k1[NB2], b2_n3[NB2];
-  c32 w1[NB1], w2[NB2];
+  const float2* tw;
   float2* lds2;
   float* lds1;
 
   // tw: the table W_N^k = (cos, -sin)(2 pi k / N), k < N, that tfft_initialize builds; lds: a
   // workgroup-shared buffer of P::LDS_BYTES bytes, 16-byte aligned.
-  __device__ __forceinline__ BlockFFT(const float2* __restrict__ tw, char* lds) {
+  __device__ __forceinline__ BlockFFT(const float2* __restrict__ tw_, char* lds) {
     tid = threadIdx.x;
     hi = (tid >> 5) & 1;
+    tw = tw_;
     lds2 = reinterpret_cast<float2*>(lds);
     lds1 = reinterpret_cast<float*>(lds);
-    if constexpr (NB1 == 1) {
-      const int g = pair_swizzle(tid);
-      b1_tr[0] = g / C1;
-      b1_c[0] = g % C1;
-      ld_tr[0] = b1_tr[0];
-      ld_base[0] = (b1_tr[0] * N + hi * (R1 / 2) * C1 + (b1_c[0] & ~1)) >> 1;
-    } else {
-#pragma unroll
-      for (int pi = 0; pi < NB1 / 2; ++pi) {
-        const int g = 2 * (tid + WG * pi);
-        b1_tr[2 * pi] = b1_tr[2 * pi + 1] = g / C1;
-        b1_c[2 * pi] = g % C1;
-        b1_c[2 * pi + 1] = b1_c[2 * pi] + 1;
-        ld_tr[pi] = g / C1;
-        ld_base[pi] = (ld_tr[pi] * N + b1_c[2 * pi]) >> 1;
-      }
-    }
-    if constexpr (NBL == 1) {
-      const int g = pair_swizzle(tid);
-      bl_tr[0] = g / CL;
-      bl_q[0] = g % CL;
-      st_tr[0] = bl_tr[0];
-      st_base[0] = (bl_tr[0] * N + hi * (RL / 2) * CL + (bl_q[0] & ~1)) >> 1;
-    } else {
-#pragma unroll
-      for (int pi = 0; pi < NBL / 2; ++pi) {
-        const int g = 2 * (tid + WG * pi);
-        bl_tr[2 * pi] = bl_tr[2 * pi + 1] = g / CL;
-        bl_q[2 * pi] = g % CL;
-        bl_q[2 * pi + 1] = bl_q[2 * pi] + 1;
-        st_tr[pi] = g / CL;
-        st_base[pi] = (st_tr[pi] * N + bl_q[2 * pi]) >> 1;
-      }
-    }
-    if constexpr (P::PASSES == 3) {
-#pragma unroll
-      for (int b = 0; b < NB2; ++b) {
-        const int g = tid + WG * b;
-        b2_tr[b] = g / C2;
-        const int q = g % C2;
-        b2_k1[b] = q / R3;
-        b2_n3[b] = q % R3;
-      }
-    }
-    if (tw != nullptr) {
-#pragma unroll
-      for (int b = 0; b < NB1; ++b) w1[b] = tw[b1_c[b]];
-      if constexpr (P::PASSES == 3) {
-#pragma unroll
-        for (int b = 0; b < NB2; ++b) w2[b] = tw[b2_n3[b] * R1];
-      }
-    }
+  }
+
+  // ---- butterflies of a thread. First and last pass: butterfly b handles column g % C of
+  // transform g / C, lanes l and l+32 (one butterfly per thread) or registers 2i, 2i+1 (several)
+  // on adjacent columns; middle pass: butterfly (k1, n3).
+  template <int NB>
+  __device__ __forceinline__ int edge_g(int b) const {
+    if constexpr (NB == 1) return pair_swizzle(tid);
+    return 2 * (tid + WG * (b >> 1)) + (b & 1);
+  }
+  __device__ __forceinline__ int b1_tr(int b) const { return edge_g<NB1>(b) / C1; }
+  __device__ __forceinline__ int b1_c(int b) const { return edge_g<NB1>(b) % C1; }
+  __device__ __forceinline__ int bl_tr(int b) const { return edge_g<NBL>(b) / CL; }
+  __device__ __forceinline__ int bl_q(int b) const { return edge_g<NBL>(b) % CL; }
+  __device__ __forceinline__ int b2_tr(int b) const { return (tid + WG * b) / C2; }
+  __device__ __forceinline__ int b2_k1(int b) const { return ((tid + WG * b) % C2) / R3; }
+  __device__ __forceinline__ int b2_n3(int b) const { return ((tid + WG * b) % C2) % R3; }
+  // raw-element offsets (two points each) of a group's first load / store, and its transform
+  __device__ __forceinline__ int ld_tr(int g) const { return b1_tr(NB1 == 1 ? 0 : 2 * g); }
+  __device__ __forceinline__ int ld_base(int g) const {
+    if constexpr (NB1 == 1) return (b1_tr(0) * N + hi * (R1 / 2) * C1 + (b1_c(0) & ~1)) >> 1;
+    return (b1_tr(2 * g) * N + b1_c(2 * g)) >> 1;
+  }
+  __device__ __forceinline__ int st_tr(int g) const { return bl_tr(NBL == 1 ? 0 : 2 * g); }
+  __device__ __forceinline__ int st_base(int g) const {
+    if constexpr (NBL == 1) return (bl_tr(0) * N + hi * (RL / 2) * CL + (bl_q(0) & ~1)) >> 1;
+    return (bl_tr(2 * g) * N + bl_q(2 * g)) >> 1;
   }
 
   // ---- which point a register holds
-  __device__ __forceinline__ int index_in(int e) const { return b1_c[e / R1] + (e % R1) * C1; }
-  __device__ __forceinline__ int transform_in(int e) const { return b1_tr[e / R1]; }
-  __device__ __forceinline__ int index_out(int e) const { return bl_q[e / RL] + (e % RL) * CL; }
-  __device__ __forceinline__ int transform_out(int e) const { return bl_tr[e / RL]; }
+  __device__ __forceinline__ int index_in(int e) const { return b1_c(e / R1) + (e % R1) * C1; }
+  __device__ __forceinline__ int transform_in(int e) const { return b1_tr(e / R1); }
+  __device__ __forceinline__ int index_out(int e) const { return bl_q(e / RL) + (e % RL) * CL; }
+  __device__ __forceinline__ int transform_out(int e) const { return bl_tr(e / RL); }
 
   // ---- global -> registers. `src` addresses this workgroup's TPB transforms ([TPB][N] points,
   // two points per raw element); transforms numbered `valid` and above read as zero.
@@ -159,8 +136,8 @@ struct BlockFFT {
   __device__ __forceinline__ void load(const typename IO::raw* src, int valid, typename IO::raw (&pre)[NRAW]) const {
 #pragma unroll
     for (int g = 0; g < NG1; ++g) {
-      const bool ok = (TPB == 1) || (ld_tr[g] < valid);
-      const typename IO::raw* p = src + ld_base[g];
+      const bool ok = (TPB == 1) || (ld_tr(g) < valid);
+      const typename IO::raw* p = src + ld_base(g);
 #pragma unroll
       for (int i = 0; i < LPG1; ++i) pre[g * LPG1 + i] = ok ? IO::load(p + i * (C1 / 2)) : IO::zero();
     }
@@ -188,11 +165,16 @@ struct BlockFFT {
 
   // ---- registers -> global, the mirror image of load + unpack
   template <class IO>
-  __device__ __forceinline__ void store(typename IO::raw* dst, int valid, const c32 (&v)[E]) const {
+  __device__ __forceinline__ void store(typename IO::raw* dst, int valid, const c32 (&vin)[E]) const {
+    // a private copy: pairing registers b*RL + i of two butterflies straight out of the caller's
+    // array leaves part of that array in scratch memory (scalar replacement gives up on it)
+    c32 v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = make_float2(vin[e].x, vin[e].y);
 #pragma unroll
     for (int g = 0; g < NGL; ++g) {
-      const bool ok = (TPB == 1) || (st_tr[g] < valid);
-      typename IO::raw* p = dst + st_base[g];
+      const bool ok = (TPB == 1) || (st_tr(g) < valid);
+      typename IO::raw* p = dst + st_base(g);
 #pragma unroll
       for (int i = 0; i < SPGL; ++i) {
         typename IO::raw r;
@@ -213,25 +195,25 @@ struct BlockFFT {
 
   // ---- LDS slots of the two exchanges (same maps as fft_lds_kernel)
   __device__ __forceinline__ int ex1_wslot(int b, int k1) const {
-    const int base = b1_tr[b] * N + b1_c[b];
+    const int base = b1_tr(b) * N + b1_c(b);
     return walk_slot<P::PS1, P::PW1, C1, R1, false>(base, pad_idx<P::PS1, P::PW1>(base), k1);
   }
   __device__ __forceinline__ int ex1_rslot(int b, int n2) const {
     if constexpr (P::PASSES == 3) {
-      const int base = b2_tr[b] * N + b2_k1[b] * C1 + b2_n3[b];
+      const int base = b2_tr(b) * N + b2_k1(b) * C1 + b2_n3(b);
       return walk_slot<P::PS1, P::PW1, R3, R2, false>(base, pad_idx<P::PS1, P::PW1>(base), n2);
     } else {
-      const int base = bl_tr[b] * N + bl_q[b] * C1;
+      const int base = bl_tr(b) * N + bl_q(b) * C1;
       return walk_slot<P::PS1, P::PW1, 1, R2, true>(base, pad_idx<P::PS1, P::PW1>(base), n2);
     }
   }
   __device__ __forceinline__ int ex2_wslot(int b, int k2) const {
-    const int base = b2_tr[b] * N + b2_k1[b] * R3 + b2_n3[b];
+    const int base = b2_tr(b) * N + b2_k1(b) * R3 + b2_n3(b);
     return walk_slot<P::PS2, P::PW2, R1 * R3, R2, false>(base, pad_idx<P::PS2, P::PW2>(base), k2);
   }
   __device__ __forceinline__ int ex2_rslot(int b, int n3) const {
-    const int k1 = bl_q[b] % R1, k2 = bl_q[b] / R1;
-    const int base = bl_tr[b] * N + k2 * (R1 * R3) + k1 * R3;
+    const int k1 = bl_q(b) % R1, k2 = bl_q(b) / R1;
+    const int base = bl_tr(b) * N + k2 * (R1 * R3) + k1 * R3;
     return walk_slot<P::PS2, P::PW2, 1, R3, true>(base, pad_idx<P::PS2, P::PW2>(base), n3);
   }
 
@@ -252,10 +234,14 @@ struct BlockFFT {
     if (lead) __syncthreads();
     if constexpr (!P::SPLIT) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) lds2[wslot<WHICH>(e)] = v[e];
+      for (int e = 0; e < E; ++e) lds2[wslot<WHICH>(e)] = make_float2(v[e].x, v[e].y);
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = lds2[rslot<WHICH>(e)];
+      for (int e = 0; e < E; ++e) {
+        const float2 t = lds2[rslot<WHICH>(e)];
+        v[e].x = t.x;
+        v[e].y = t.y;
+      }
     } else {
       float re[E];
 #pragma unroll
@@ -272,7 +258,9 @@ struct BlockFFT {
     }
   }
 
-  template <int R>
+  // radix-R butterflies on v[b*R .. b*R+R-1], then the inter-pass twiddles of set TW (0: none,
+  // 1: after the first pass, 2: after the middle pass)
+  template <int R, int TW>
   __device__ __forceinline__ void butterflies(c32 (&v)[E], const c32* w) const {
 #pragma unroll
     for (int b = 0; b < E / R; ++b) {
@@ -280,7 +268,7 @@ struct BlockFFT {
 #pragma unroll
       for (int j = 0; j < R; ++j) x[j] = v[b * R + j];
       dft<R>(x);
-      if (w != nullptr) apply_twiddles<R>(x, fresh<false>(w[b]));
+      if constexpr (TW != 0) apply_twiddles<R>(x, fresh<false>(w[b]));
 #pragma unroll
       for (int j = 0; j < R; ++j) v[b * R + j] = x[j];
     }
@@ -296,13 +284,21 @@ struct BlockFFT {
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = make_float2(v[e].y, v[e].x);
     }
-    butterflies<R1>(v, w1);
+    // twiddle bases, one per butterfly: W_N^c after the first pass, W_{R2 R3}^{n3} after the middle one
+    c32 w1[NB1], w2[NB2];
+#pragma unroll
+    for (int b = 0; b < NB1; ++b) w1[b] = tw[b1_c(b)];
+    if constexpr (P::PASSES == 3) {
+#pragma unroll
+      for (int b = 0; b < NB2; ++b) w2[b] = tw[b2_n3(b) * R1];
+    }
+    butterflies<R1, 1>(v, w1);
     exchange<1>(v, lead);
     if constexpr (P::PASSES == 3) {
-      butterflies<R2>(v, w2);
+      butterflies<R2, 2>(v, w2);
       exchange<2>(v, true);
     }
-    butterflies<RL>(v, nullptr);
+    butterflies<RL, 0>(v, nullptr);
     if constexpr (!FWD) {
 #pragma unroll
       for (int e = 0; e < E; ++e) v[e] = make_float2(v[e].y, v[e].x);

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_real_pair_kernel(cons
     v[2 * j + 1] = cmul(v[2 * j + 1], h1);
   }
   f.template transform<false>(v, true);
-  unsigned* p0 = y + s0 * (N / 2) + f.st_base[0];
-  unsigned* p1 = y + s1 * (N / 2) + f.st_base[0];
+  unsigned* p0 = y + s0 * (N / 2) + f.st_base(0);
+  unsigned* p1 = y + s1 * (N / 2) + f.st_base(0);
 #pragma unroll
   for (int i = 0; i < NRAW; ++i) {
     c32 a = v[i], b = v[i + RL / 2];

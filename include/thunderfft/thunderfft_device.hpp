@@ -91,7 +91,10 @@ __device__ __forceinline__ void ThunderFFT_reg2gmem(const DeviceFFT<N>& fft, vec
                                                     const float2 (&reg)[elements_per_thread<N>],
                                                     int valid = batch_per_block<N>) {
   using IO = typename device_io<T>::type;
-  fft.template store<IO>(reinterpret_cast<typename IO::raw*>(gmem), valid, reg);
+  float2 tmp[elements_per_thread<N>];
+#pragma unroll
+  for (int e = 0; e < elements_per_thread<N>; ++e) tmp[e] = reg[e];
+  fft.template store<IO>(reinterpret_cast<typename IO::raw*>(gmem), valid, tmp);
 }
 
 // Register-resident transform (reference: ThunderFFT_kernel_reg<T, N, batch, forward>(reg, W,

@@ -9,9 +9,9 @@ for line in open(sys.argv[1]):
     if line.startswith("###"):
         m = re.search(r"--mode (\d+)", line)
         key = ("m" + (m.group(1) if m else "0")) + ("/oop" if "--inplace 0" in line else "/ip")
-    m = re.match(r"thunderfft\S*\s+(\d+)\s+(\S+)\s+\d+\s+\S+\s+(\S+)\s+\S+\s+\S+\s+(\S+)%", line)
-    if m:
-        runs[(int(m.group(1)), key)].append(float(m.group(4)))
+    if line.startswith("thunderfft"):
+        tok = line.split()
+        runs[(int(tok[1]), key)].append(float(tok[-1].rstrip("%")))
 ns = sorted({k[0] for k in runs})
 keys = sorted({k[1] for k in runs})
 print("N     ", *[f"{k:>8s}" for k in keys])
