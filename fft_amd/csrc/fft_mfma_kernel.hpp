@@ -1,0 +1,261 @@
+// N = 4096, fp16 storage: all three radix-16 passes on the matrix cores.
+//
+// The reference computes its transforms as tensor-core products of small DFT matrices with
+// fragments of the data (thunderfft/include/thunderfft/detail/kernel/unit_kernel_fp16.cuh:97-238,
+// mma.m16n8k8 with fp16 accumulation). This is the wave64 counterpart for gfx950: one
+// v_mfma_f32_16x16x32_f16 multiplies the real-ified 16-point DFT matrix (16 x 32: rows = output
+// index, K = 16 points x (re, im)) by 16 columns of fp16 data, fp32 accumulation; two of them (real
+// and imaginary output rows) transform 16 columns. 4096 = 16 x 16 x 16, n = 256 n1 + 16 n2 + n3,
+// k = k1 + 16 k2 + 256 k3, decimation in frequency like the VALU kernels:
+//
+//   pass 1 over n1, twiddle W_4096^(k1 (16 n2 + n3)); pass 2 over n2, twiddle W_256^(k2 n3); pass 3 over n3.
+//
+// Fragment layouts (lane l = 16 g + i): the B operand of lane (g, i) is points 4g .. 4g+3 of column
+// i -- four (re, im) fp16 pairs, 16 contiguous bytes when the contracted axis is fastest; the
+// result D gives the same lane outputs 4g .. 4g+3 of column i. So every pass needs its input with
+// the contracted axis fastest:
+//   * pass 1 takes it from registers: a lane loads 16 bytes (four adjacent columns of one row) for
+//     four rows, and a 4 x 4 transpose across lanes l, l+16, l+32, l+48 (two v_permlane32_swap and
+//     two v_permlane16_swap per column) leaves it with four consecutive rows of each column;
+//   * passes 2 and 3 read 16-byte granules (ds_read_b128) from an LDS image [column][point] that the
+//     previous pass wrote dword by dword; the image has no padding, its four granules per row are
+//     rotated by a function of the row chosen by tools/lds_mfma_layout.py so that every read is
+//     conflict-free and every write at most 2-way (free for ds_write_b32);
+//   * the output goes through a natural-order image so that global stores are 16 bytes per lane.
+// Data is rounded to fp16 between passes (the storage type's own precision); twiddles and
+// accumulation are fp32. Intermediate values must fit fp16, i.e. N * max|x| < 65504 -- the bound
+// that also keeps the fp16 result finite.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "fft_lds_kernel.hpp"
+
+namespace tfft {
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+struct Mfma4096 {
+  static constexpr int N = 4096, WG = 256;
+  static constexpr int IMG = 4096;            // dwords of a pass image
+  static constexpr int OUT_IMG = 4096 + 64;   // natural-order output image, 4 dwords of pad per 256
+  static constexpr int TW_LANE_ORDER = 4096;  // float2 entries appended to the twiddle table: pass-1 twiddles
+  static constexpr int FRAG_TABLE = 1024;     // then, per direction: matrix fragments and pass-2 twiddles per lane
+};
+
+// Host side: the pass-1 twiddles in the order the kernel's lanes consume them. Entry
+// [(j*2 + rp) * 256 + tid] holds the float4 { W^(k1 c), W^((k1+1) c) } with tid = 64 w + 16 g + i,
+// k1 = 4 g + 2 rp, c = 64 w + 4 i + j, W = exp(-2 pi i / 4096).
+inline unsigned short mfma_host_half(float f) {  // round to nearest even; |f| <= 1, no subnormal results here
+  unsigned u;
+  memcpy(&u, &f, 4);
+  const unsigned sign = (u >> 16) & 0x8000u;
+  const unsigned mag = u & 0x7fffffffu;
+  if (mag < 0x38800000u) return (unsigned short)sign;  // below the smallest normal half: the tables only hold 0 there
+  const unsigned rounded = mag + 0xfffu + ((mag >> 13) & 1u);
+  return (unsigned short)(sign | ((rounded - 0x38000000u) >> 13));
+}
+
+inline void mfma4096_lane_twiddles(float2* dst) {
+  for (int j = 0; j < 4; ++j)
+    for (int rp = 0; rp < 2; ++rp)
+      for (int tid = 0; tid < 256; ++tid) {
+        const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+        const int c = 64 * w + 4 * i + j;
+        for (int h = 0; h < 2; ++h) {
+          const int k1 = 4 * g + 2 * rp + h;
+          const double a = -2.0 * M_PI * (double)((k1 * c) & 4095) / 4096.0;
+          dst[(((j * 2 + rp) * 256) + tid) * 2 + h] = make_float2((float)cos(a), (float)sin(a));
+        }
+      }
+  // Per direction d (0 forward, 1 inverse), 16-byte entry [d*256 + q*64 + l] of lane l = 16 g + i:
+  //   q = 0: row i of the real-output matrix, K = 8g .. 8g+7 as fp16: (cos, +-sin) per point m = 4g + jj
+  //   q = 1: row i of the imaginary-output matrix: (-+sin, cos)
+  //   q = 2, 3: the pass-2 twiddles W_256^((4g + r) i), r = 0..3, as fp32 (cos, -sin)
+  unsigned char* base = reinterpret_cast<unsigned char*>(dst + Mfma4096::TW_LANE_ORDER);
+  for (int d = 0; d < 2; ++d)
+    for (int l = 0; l < 64; ++l) {
+      const int g = l >> 4, i = l & 15;
+      unsigned short are[8], aim[8];
+      for (int jj = 0; jj < 4; ++jj) {
+        const double a = 2.0 * M_PI * (double)((i * (4 * g + jj)) & 15) / 16.0;
+        const float c = (float)cos(a), sn = (float)(d == 0 ? sin(a) : -sin(a));
+        are[2 * jj] = mfma_host_half(c);
+        are[2 * jj + 1] = mfma_host_half(sn);
+        aim[2 * jj] = mfma_host_half(-sn);
+        aim[2 * jj + 1] = mfma_host_half(c);
+      }
+      float t2[8];
+      for (int r = 0; r < 4; ++r) {
+        const double a = -2.0 * M_PI * (double)((4 * g + r) * i) / 256.0;
+        t2[2 * r] = (float)cos(a);
+        t2[2 * r + 1] = (float)sin(a);
+      }
+      memcpy(base + 16 * (d * 256 + 0 * 64 + l), are, 16);
+      memcpy(base + 16 * (d * 256 + 1 * 64 + l), aim, 16);
+      memcpy(base + 16 * (d * 256 + 2 * 64 + l), t2, 16);
+      memcpy(base + 16 * (d * 256 + 3 * 64 + l), t2 + 4, 16);
+    }
+}
+
+__device__ __forceinline__ unsigned pack_f16(float re, float im) {
+  const __half2 h = __float22half2_rn(make_float2(re, im));
+  return *reinterpret_cast<const unsigned*>(&h);
+}
+
+// DOUBLE: two LDS images (33 KiB, three barriers) instead of one (16.6 KiB, five barriers).
+// PERSIST: a resident grid; a workgroup walks transforms blockIdx.x, blockIdx.x + gridDim.x, ... and
+// requests the rows of its next transform as soon as the current rows are packed into fragments, so
+// that its HBM requests stay in flight under the three passes (16 more live VGPRs).
+template <bool FWD, bool DOUBLE, int MINW, bool PERSIST = false>
+__global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4_t* __restrict__ in,
+                                                                     u32x4_t* __restrict__ out,
+                                                                     const float2* __restrict__ tw, long long batch) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + (DOUBLE ? Mfma4096::IMG : 0)];
+  unsigned* const img_a = lds;                                      // pass-2 input, later the output image
+  unsigned* const img_b = DOUBLE ? lds + Mfma4096::OUT_IMG : lds;   // pass-3 input
+
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+  long long tr = blockIdx.x;
+  if (tr >= batch) return;
+
+  // ---- rows first: lane (g, i) of wave w loads rows n1 = 4G + g, columns 64w + 4i .. 4i+3
+  u32x4_t rows[4];
+  auto request_rows = [&](long long t) {
+    const u32x4_t* src = in + t * 1024 + 16 * w + i;
+#pragma unroll
+    for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
+  };
+  request_rows(tr);
+
+  // ---- pass-1 twiddles in lane order, the DFT-16 matrix fragments, the pass-2 twiddles
+  const float4* tw1 = reinterpret_cast<const float4*>(tw + Mfma4096::N) + tid;
+  float4 t1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t1[e] = tw1[e * 256];
+  const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) +
+                        (FWD ? 0 : 256) + (tid & 63);
+  const mfma_h8 a_re = __builtin_bit_cast(mfma_h8, ftab[0]);
+  const mfma_h8 a_im = __builtin_bit_cast(mfma_h8, ftab[64]);
+  c32 t2[4];
+  {
+    const u32x4_t p = ftab[128], q = ftab[192];
+    t2[0] = make_float2(__uint_as_float(p.x), __uint_as_float(p.y));
+    t2[1] = make_float2(__uint_as_float(p.z), __uint_as_float(p.w));
+    t2[2] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+    t2[3] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
+  }
+
+  auto twiddle = [](float re, float im, c32 t) {
+    // (re + i im) * t forward, * conj(t) inverse; t = (cos, -sin)
+    if (FWD) return make_float2(re * t.x - im * t.y, re * t.y + im * t.x);
+    return make_float2(re * t.x + im * t.y, im * t.x - re * t.y);
+  };
+  const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  for (;;) {
+  // ---- pass 1: transpose rows <-> lane groups, then 16 columns {64w + 4i + j} per j
+  u32x4_t packed[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned a0 = rows[0][j], a1 = rows[1][j], a2 = rows[2][j], a3 = rows[3][j];
+    auto s = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+    a0 = s[0]; a2 = s[1];
+    s = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+    a1 = s[0]; a3 = s[1];
+    s = __builtin_amdgcn_permlane16_swap(a0, a1, false, false);
+    a0 = s[0]; a1 = s[1];
+    s = __builtin_amdgcn_permlane16_swap(a2, a3, false, false);
+    a2 = s[0]; a3 = s[1];
+    packed[j] = u32x4_t{a0, a1, a2, a3};  // rows 4g .. 4g+3 of column 64w + 4i + j
+  }
+  const long long next = tr + gridDim.x;
+  if (PERSIST && next < batch) request_rows(next);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const mfma_h8 b = __builtin_bit_cast(mfma_h8, packed[j]);
+    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_re, b, zero, 0, 0, 0);
+    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_im, b, zero, 0, 0, 0);
+    // lane holds Y1[k1 = 4g + r][n2 = 4w + (i >> 2)][n3 = 4 (i & 3) + j]; image 2 row = (k1, n3), point n2
+    const int n2 = 4 * w + (i >> 2);
+    const int rot = (2 * (i & 3) + (j >> 1) + g) & 3;
+    const int pos = (n2 + 4 * rot) & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 tt = t1[j * 2 + (r >> 1)];
+      const c32 t = (r & 1) ? make_float2(tt.z, tt.w) : make_float2(tt.x, tt.y);
+      const c32 y = twiddle(cr[r], ci[r], t);
+      const int row = (4 * g + r) * 16 + 4 * (i & 3) + j;
+      img_a[row * 16 + pos] = pack_f16(y.x, y.y);
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2: wave w owns k1 = 4w + t; column n3 = i, points n2 = 4g .. 4g+3
+  u32x4_t frag[4];
+  {
+    const int rot = ((i >> 1) + w) & 3;
+    const int gran = (g + rot) & 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      frag[t] = *reinterpret_cast<const u32x4_t*>(&img_a[((4 * w + t) * 16 + i) * 16 + 4 * gran]);
+  }
+  if (!DOUBLE) __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const mfma_h8 b = __builtin_bit_cast(mfma_h8, frag[t]);
+    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_re, b, zero, 0, 0, 0);
+    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_im, b, zero, 0, 0, 0);
+    // lane holds Y2[k1 = 4w + t][k2 = 4g + r][n3 = i]; image 3 row = (k2, k1), point n3
+    const int rot = (t + 2 * w + (t >> 1)) & 3;
+    const int pos = (i + 4 * rot) & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const c32 y = twiddle(cr[r], ci[r], t2[r]);
+      const int row = (4 * g + r) * 16 + 4 * w + t;
+      img_b[row * 16 + pos] = pack_f16(y.x, y.y);
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 3: wave w owns k2 = 4w + t; column k1 = i, points n3 = 4g .. 4g+3
+  {
+    const int rot = (i + (i >> 1)) & 3;
+    const int gran = (g + rot) & 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      frag[t] = *reinterpret_cast<const u32x4_t*>(&img_b[((4 * w + t) * 16 + i) * 16 + 4 * gran]);
+  }
+  if (!DOUBLE) __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const mfma_h8 b = __builtin_bit_cast(mfma_h8, frag[t]);
+    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_re, b, zero, 0, 0, 0);
+    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_im, b, zero, 0, 0, 0);
+    // lane holds X[k = i + 16 (4w + t) + 256 (4g + r)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k3 = 4 * g + r;
+      img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = pack_f16(cr[r], ci[r]);
+    }
+  }
+  __syncthreads();
+
+  // ---- natural order out, 16 bytes per lane
+  u32x4_t* dst = out + tr * 1024 + tid;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
+    __builtin_nontemporal_store(v, dst + 256 * q);
+  }
+  if (!PERSIST || next >= batch) break;
+  __syncthreads();  // the output image is read before the next transform's pass 1 overwrites it
+  tr = next;
+  }
+}
+
+}  // namespace tfft

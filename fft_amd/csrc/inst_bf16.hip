@@ -9,7 +9,7 @@ bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
     case 512: return entry_for<Plan512, StoreBF16, false>(forward, mode, out);
     case 1024: return entry_for<Plan1024, StoreBF16, false>(forward, mode, out);
     case 2048: return entry_for<Plan2048, StoreBF16, false>(forward, mode, out);
-    case 4096: return entry_for<Plan4096, StoreBF16, true, Plan4096Mfma>(forward, mode, out);
+    case 4096: return entry_for<Plan4096, StoreBF16, true, Plan4096Mfma, Plan4096ResidentSplit>(forward, mode, out);
     case 8192: return entry_for<Plan8192, StoreBF16, false>(forward, mode, out);
     case 16384: return entry_for<Plan16384, StoreBF16, false>(forward, mode, out);
     default: return false;

@@ -9,7 +9,20 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
     case 512: return entry_for<Plan512, StoreF16, false>(forward, mode, out);
     case 1024: return entry_for<Plan1024, StoreF16, false>(forward, mode, out);
     case 2048: return entry_for<Plan2048, StoreF16, false>(forward, mode, out);
-    case 4096: return entry_for<Plan4096, StoreF16, true, Plan4096Mfma>(forward, mode, out);
+    case 4096:
+      // Default: all three passes on the matrix cores, resident grid with row prefetch, two LDS images
+      // (fft_mfma_kernel.hpp). Mode 3: the VALU kernel; 4: VALU with the middle pass on the matrix
+      // cores; 5 / 6: matrix cores, one workgroup per transform, one / two LDS images; 7: resident with
+      // one LDS image; 9: VALU kernel as a resident prefetching grid.
+      if (mode == 0) { *out = forward ? make_mfma_entry<true, true, 4, true>() : make_mfma_entry<false, true, 4, true>(); return true; }
+      if (mode == 5) { *out = forward ? make_mfma_entry<true, false, 4>() : make_mfma_entry<false, false, 4>(); return true; }
+      if (mode == 6) { *out = forward ? make_mfma_entry<true, true, 4>() : make_mfma_entry<false, true, 4>(); return true; }
+      if (mode == 7) { *out = forward ? make_mfma_entry<true, false, 4, true>() : make_mfma_entry<false, false, 4, true>(); return true; }
+      if (mode == 3) mode = 0;
+      else if (mode == 4) mode = 3;
+      else if (mode == 9) mode = 4;
+      else if (mode != 1 && mode != 2) return false;
+      return entry_for<Plan4096, StoreF16, true, Plan4096Mfma, Plan4096ResidentSplit>(forward, mode, out);
     case 8192: return entry_for<Plan8192, StoreF16, false>(forward, mode, out);
     case 16384: return entry_for<Plan16384, StoreF16, false>(forward, mode, out);
     default: return false;

@@ -7,6 +7,7 @@
 // shared-memory layouts (thunderfft/include/thunderfft/thunderfft_layout_tuned.h:6-97).
 #pragma once
 #include "fft_lds_kernel.hpp"
+#include "fft_mfma_kernel.hpp"
 
 namespace tfft {
 
@@ -79,6 +80,7 @@ using Plan16384 = Plan16384Split; using Plan16384Alt = Plan16384Full;
 
 // A resident, software-pipelined walk of the batch (prefetches the next chunk's rows); measured
 // slower than one workgroup per chunk on MI355X and kept for that comparison only.
+using Plan4096ResidentSplit = Plan<4096, 16, 16, 16, 16, 256, 8, 16, 5, 1, 5, kFlagSplit | kFlagPrefetch>;
 using Plan4096Resident = Plan<4096, 16, 16, 16, 16, 256, 4, 1, 5, 1, 1, kFlagPrefetch>;
 
 // What the host needs to launch one instantiation.
@@ -87,6 +89,7 @@ struct KernelEntry {
   void (*launch)(const void* in, void* out, const float2* tw, long long batch, long long nchunks,
                  unsigned grid, unsigned extra_lds, hipStream_t stream);
   int n, threads, tpb, e, radix[3], lds_bytes;
+  int resident_per_cu = 0;  // > 0: a resident grid of this many workgroups per CU is the kernel's default launch
 };
 
 template <class P, class IO, bool FWD, int MODE>
@@ -114,6 +117,34 @@ KernelEntry make_entry() {
   e.radix[1] = P::R2;
   e.radix[2] = P::R3;
   e.lds_bytes = P::LDS_BYTES;
+  return e;
+}
+
+// Matrix-core kernel of fft_mfma_kernel.hpp as a table entry (one transform per workgroup).
+template <bool FWD, bool DOUBLE, int MINW, bool PERSIST>
+void launch_mfma4096(const void* in, void* out, const float2* tw, long long batch, long long nchunks, unsigned grid,
+                     unsigned extra_lds, hipStream_t stream) {
+  (void)nchunks;
+  (void)extra_lds;
+  // one-shot: one workgroup per transform; resident: the caller's grid (workgroups per CU x CUs)
+  const unsigned blocks = PERSIST ? grid : (unsigned)batch;
+  fft_mfma4096_f16_kernel<FWD, DOUBLE, MINW, PERSIST><<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(
+      static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch);
+}
+
+template <bool FWD, bool DOUBLE, int MINW, bool PERSIST = false>
+KernelEntry make_mfma_entry() {
+  KernelEntry e;
+  e.fn = reinterpret_cast<const void*>(&fft_mfma4096_f16_kernel<FWD, DOUBLE, MINW, PERSIST>);
+  e.launch = &launch_mfma4096<FWD, DOUBLE, MINW, PERSIST>;
+  e.n = Mfma4096::N;
+  e.threads = Mfma4096::WG;
+  e.tpb = 1;
+  e.e = 16;
+  e.radix[0] = e.radix[1] = e.radix[2] = 16;
+  e.lds_bytes = 4 * (Mfma4096::OUT_IMG + (DOUBLE ? Mfma4096::IMG : 0));
+  // three workgroups per CU measured best for the resident form (two: 66 %, three: 72-75 %, four: 67 %)
+  e.resident_per_cu = PERSIST ? 3 : 0;
   return e;
 }
 

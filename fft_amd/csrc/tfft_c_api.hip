@@ -67,6 +67,7 @@ struct Options {
   long long mode = 0;
   long long sync = 0;
   long long extra_lds = 0;
+  long long grid_blocks = 0;  // absolute resident grid size; overrides grid_blocks_per_cu
 };
 
 std::mutex g_mu;
@@ -223,14 +224,17 @@ int tfft_initialize(int dtype, int n) {
   if (g_plans.count(key)) return TFFT_OK;
 
   DevicePlan p;
-  std::vector<float2> h(n);
+  // n = 4096: the table is followed by the lane-ordered tables of the matrix-core kernel
+  const size_t entries = (size_t)n + (n == tfft::Mfma4096::N ? tfft::Mfma4096::TW_LANE_ORDER + tfft::Mfma4096::FRAG_TABLE : 0);
+  std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
     // exact reduction of the angle: j/n is a dyadic rational, evaluated in fp64 and rounded once
     const double a = -2.0 * M_PI * (double)j / (double)n;
     h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
   }
-  TFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p.tw), sizeof(float2) * n));
-  hipError_t e = hipMemcpy(p.tw, h.data(), sizeof(float2) * n, hipMemcpyHostToDevice);
+  if (n == tfft::Mfma4096::N) tfft::mfma4096_lane_twiddles(h.data() + n);
+  TFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p.tw), sizeof(float2) * entries));
+  hipError_t e = hipMemcpy(p.tw, h.data(), sizeof(float2) * entries, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     (void)hipFree(p.tw);
     return fail(TFFT_ERR_HIP, "hipMemcpy(twiddle): %s", hipGetErrorString(e));
@@ -326,6 +330,7 @@ int tfft_set_option(const char* key, long long value) {
   else if (!strcmp(key, "mode")) g_opt.mode = value;
   else if (!strcmp(key, "sync")) g_opt.sync = value;
   else if (!strcmp(key, "extra_lds")) g_opt.extra_lds = value;
+  else if (!strcmp(key, "grid_blocks")) g_opt.grid_blocks = value;
   else return fail(TFFT_ERR_INVALID, "tfft_set_option: unknown key '%s'", key);
   return TFFT_OK;
 }
@@ -437,7 +442,9 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
   // order as workgroups retire, which streams HBM measurably better than a resident grid walking
   // the batch with a stride; "grid_blocks_per_cu" selects the resident (persistent) form instead.
   long long grid = nchunks;
+  if (e.resident_per_cu > 0) grid = (long long)e.resident_per_cu * plan.cu_count;
   if (opt.grid_blocks_per_cu > 0) grid = opt.grid_blocks_per_cu * plan.cu_count;
+  if (opt.grid_blocks > 0) grid = opt.grid_blocks;
   if (grid > nchunks) grid = nchunks;
   if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -199,6 +199,43 @@ def test_alternative_plans_vs_oracle(oracle_mod, n, mode):
         fft_amd.set_option("grid_blocks_per_cu", 0)
 
 
+@pytest.mark.parametrize("mode", [0, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("forward", (True, False))
+def test_fp16_4096_plans_vs_oracle(oracle_mod, mode, forward):
+    """fp16 storage, N = 4096. Mode 0 (default), 5, 6, 7: all three passes on the matrix cores (fp16
+    operands, fp32 accumulation, data rounded to fp16 between passes), as a resident prefetching grid
+    (0, 7) or one workgroup per transform (5, 6); mode 3: the fp32 VALU kernel; mode 4: VALU with the
+    middle pass on the matrix cores. Same gate for all, and a tighter regression bound."""
+    n = 4096
+    batch = 2500 if mode in (0, 7) else 37  # resident grids: several transforms per workgroup, uneven tail
+    x = synth.uniform_complex(batch, n, seed=mode) / np.sqrt(n)  # the reference's input scale, sample/bench/main.cu:36
+    try:
+        fft_amd.set_option("mode", mode)
+        if mode == 7:
+            fft_amd.set_option("grid_blocks_per_cu", 2)
+        got, stored = run(x.astype(np.complex64), "fp16", forward)
+    finally:
+        fft_amd.set_option("mode", 0)
+        fft_amd.set_option("grid_blocks_per_cu", 0)
+    ref = oracle_mod.fft(stored, forward)
+    err = oracle_mod.rel_l2(got, ref)
+    print(f"mode={mode} forward={forward} rel_l2={err:.3e}")
+    assert err <= TOL["fp16"], f"mode={mode} forward={forward} rel_l2={err:.3e}"
+    assert err <= 3e-3, f"accuracy regressed: mode={mode} rel_l2={err:.3e}"
+    # every transform on its own: a misplaced row or column would hide in the aggregate
+    worst = max(oracle_mod.rel_l2(got[b], ref[b]) for b in range(batch))
+    assert worst <= TOL["fp16"], worst
+
+
+def test_fp16_4096_in_place_and_small_batches(oracle_mod):
+    # the default fp16 kernel is a resident grid: in place, and batches smaller than the grid
+    n = 4096
+    for batch in (1, 3, 700, 1000):
+        x = (synth.uniform_complex(batch, n, seed=batch) / np.sqrt(n)).astype(np.complex64)
+        got, stored = run(x, "fp16", True, inplace=True)
+        assert oracle_mod.rel_l2(got, oracle_mod.fft(stored, True)) <= 3e-3, batch
+
+
 def test_resident_grid_matches_one_shot():
     # the same kernel walked by a resident grid (each workgroup loops over chunks) is bit-identical
     n, batch = 1024, 5000
