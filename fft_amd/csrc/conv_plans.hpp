@@ -17,7 +17,9 @@ struct ConvEntry {
   int n, threads, points_per_thread, lds_bytes;
 };
 
-bool lookup_conv(int dtype, int n, int kind, ConvEntry* out);
+// mode 0: the default kernel of (dtype, n, kind); mode 3: the fp32-VALU kernel where the default runs on the
+// matrix cores (fp16 storage). Filter layout and execution must be looked up with the same mode.
+bool lookup_conv(int dtype, int n, int kind, int mode, ConvEntry* out);
 
 // Overlap-save tiles of length n, `valid` outputs kept per tile.
 struct ConvTilesEntry {

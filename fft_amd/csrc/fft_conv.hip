@@ -11,6 +11,7 @@
 // served by L2 to the B signals that use it.
 #include "conv_plans.hpp"
 #include "fft_block.hpp"
+#include "fft_conv_mfma.hpp"
 #include "../../include/thunderfft_c.h"
 
 namespace tfft {
@@ -264,11 +265,35 @@ bool lookup_conv_plan(int dtype, int kind, ConvEntry* out) {
   return false;
 }
 
-bool lookup_conv(int dtype, int n, int kind, ConvEntry* out) {
-  switch (n) {
-    case 4096: return lookup_conv_plan<ConvPlan4096>(dtype, kind, out);
-    default: return false;
+template <int KIND>
+void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
+  const unsigned nb = (KIND == kConvMfmaRealPair) ? ((unsigned)B + 1u) / 2u : (unsigned)B;
+  fft_conv_mfma4096_kernel<KIND><<<dim3(nb * (unsigned)D), dim3(256), 0, stream>>>(x, static_cast<const u32x4_t*>(hp), y,
+                                                                                     tw, B, D);
+}
+
+void launch_layout_mfma(const void* h, void* hp, int D, hipStream_t stream) {
+  conv_mfma4096_filter_layout_kernel<0><<<dim3((unsigned)D), dim3(256), 0, stream>>>(static_cast<const unsigned*>(h),
+                                                                                   static_cast<u32x4_t*>(hp), D);
+}
+
+bool lookup_conv(int dtype, int n, int kind, int mode, ConvEntry* out) {
+  if (n != 4096) return false;
+  if (dtype == TFFT_F16 && mode != 3) {
+    // fp16 storage: both transforms on the matrix cores (fft_conv_mfma.hpp)
+    out->n = 4096;
+    out->threads = 256;
+    out->points_per_thread = 16;
+    out->lds_bytes = 4 * (Mfma4096::OUT_IMG + Mfma4096::IMG);
+    out->layout = &launch_layout_mfma;
+    switch (kind) {
+      case kConvComplex: out->launch = &launch_conv_mfma<kConvMfmaComplex>; return true;
+      case kConvRealIn: out->launch = &launch_conv_mfma<kConvMfmaRealIn>; return true;
+      case kConvRealInOut: out->launch = &launch_conv_mfma<kConvMfmaRealPair>; return true;
+      default: return false;
+    }
   }
+  return lookup_conv_plan<ConvPlan4096>(dtype, kind, out);
 }
 
 }  // namespace tfft

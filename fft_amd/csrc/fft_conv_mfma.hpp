@@ -1,0 +1,298 @@
+// Fused circular convolution, N = 4096, fp16 storage, on the matrix cores:
+//   y = IDFT( DFT(x) * H ),  both transforms as three v_mfma_f32_16x16x32_f16 radix-16 passes
+// (fragment layouts, LDS images and their granule rotation: fft_mfma_kernel.hpp).
+//
+// Counterpart of the reference's thunder_conv4096_block_kernel family
+// (thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:148-292), which likewise runs
+// ThunderFFT_kernel_reg forward, multiplies by the permuted filter spectrum in registers and runs
+// the inverse without leaving the register file (:178-189). Here the third forward pass leaves lane
+// (g, i) of wave w with X[k = i + 16 (4w + t) + 256 (4g + r)], r = 0..3 for t = 0..3: four consecutive
+// values along the inverse transform's first axis (stride 256) for column 16 (4w + t) + i, which is
+// exactly the B fragment of the inverse's first pass. The product with H (stored in that lane
+// order) is rounded to fp16 and fed straight back into the matrix cores.
+//
+// Pass-1 twiddles W_4096^(k1 c) are built incrementally, W^(k1 (c0 + s)) = W^(k1 c0) * (W^(k1 q))^s,
+// from 4 start values per lane and 4 step values per lane group, so that the tables a workgroup
+// reads stay small (16 KiB for both column maps) instead of one value per point.
+#pragma once
+#include "fft_mfma_kernel.hpp"
+
+namespace tfft {
+
+struct ConvMfma4096 {
+  // float2 entries appended after Mfma4096's tables
+  static constexpr int TABLE = 2 * (512 + 512 + 8 + 8);
+  static constexpr int OFFSET = Mfma4096::N + Mfma4096::TW_LANE_ORDER + Mfma4096::FRAG_TABLE;
+};
+
+// Host side. float4 units: start_global [h][tid] (512), start_chain [h][tid] (512), step_global [h][g] (8),
+// step_chain [h][g] (8); entry = { W^(e(k1)), W^(e(k1 + 1)) } with k1 = 4g + 2h, forward sign (cos, -sin).
+inline void conv_mfma4096_tables(float2* dst) {
+  auto w = [](long long e) {
+    const double a = -2.0 * M_PI * (double)(e & 4095) / 4096.0;
+    return make_float2((float)cos(a), (float)sin(a));
+  };
+  for (int h = 0; h < 2; ++h)
+    for (int tid = 0; tid < 256; ++tid) {
+      const int wv = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+      for (int u = 0; u < 2; ++u) {
+        const int k1 = 4 * g + 2 * h + u;
+        dst[2 * (h * 256 + tid) + u] = w((long long)k1 * (64 * wv + 4 * i));        // columns 64w + 4i + j
+        dst[2 * (512 + h * 256 + tid) + u] = w((long long)k1 * (64 * wv + i));      // columns 16 (4w + t) + i
+      }
+    }
+  for (int h = 0; h < 2; ++h)
+    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < 2; ++u) {
+        const int k1 = 4 * g + 2 * h + u;
+        dst[2 * (1024 + h * 4 + g) + u] = w(k1);                  // one column further
+        dst[2 * (1032 + h * 4 + g) + u] = w(16LL * k1);           // sixteen columns further
+      }
+}
+
+enum : int { kConvMfmaComplex = 0, kConvMfmaRealIn = 1, kConvMfmaRealPair = 2 };
+
+// One direction's constants: the DFT-16 matrix fragments and the pass-2 twiddles of this lane.
+template <bool FWD>
+struct MfmaDir {
+  mfma_h8 a_re, a_im;
+  __device__ __forceinline__ void init(const float2* tw, int tid) {
+    const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) +
+                          (FWD ? 0 : 256) + (tid & 63);
+    a_re = __builtin_bit_cast(mfma_h8, ftab[0]);
+    a_im = __builtin_bit_cast(mfma_h8, ftab[64]);
+  }
+  // (re + i im) * t forward, * conj(t) inverse; t = (cos, -sin)
+  static __device__ __forceinline__ c32 twiddle(float re, float im, c32 t) {
+    if (FWD) return make_float2(re * t.x - im * t.y, re * t.y + im * t.x);
+    return make_float2(re * t.x + im * t.y, im * t.x - re * t.y);
+  }
+};
+
+// Pass 1 on four fragments. CHAIN = false: fragment s holds column 64w + 4i + s (rows straight from
+// global memory); CHAIN = true: column 16 (4w + s) + i (the previous transform's output registers).
+template <bool FWD, bool CHAIN>
+__device__ __forceinline__ void mfma_pass1(const MfmaDir<FWD>& d, const u32x4_t (&packed)[4], const c32 (&start)[4],
+                                           const c32 (&step)[4], unsigned* img, int w, int g, int i) {
+  const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
+  c32 tw[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tw[r] = start[r];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const mfma_h8 b = __builtin_bit_cast(mfma_h8, packed[s]);
+    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(d.a_re, b, zero, 0, 0, 0);
+    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(d.a_im, b, zero, 0, 0, 0);
+    // image row = (k1, n3), point n2 (granules rotated by ((row >> 1) + (row >> 6)) & 3)
+    const int n2 = CHAIN ? 4 * w + s : 4 * w + (i >> 2);
+    const int n3 = CHAIN ? i : 4 * (i & 3) + s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const c32 y = MfmaDir<FWD>::twiddle(cr[r], ci[r], tw[r]);
+      const int row = (4 * g + r) * 16 + n3;
+      const int rot = ((n3 >> 1) + g) & 3;
+      img[row * 16 + ((n2 + 4 * rot) & 15)] = pack_f16(y.x, y.y);
+      if (s < 3) tw[r] = cmul(tw[r], step[r]);
+    }
+  }
+}
+
+// Pass 2: image `src` (rows (k1, n3), points n2) to image `dst` (rows (k2, k1), points n3).
+template <bool FWD>
+__device__ __forceinline__ void mfma_pass2(const MfmaDir<FWD>& d, const c32 (&t2)[4], const unsigned* src, unsigned* dst,
+                                           int w, int g, int i) {
+  const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
+  u32x4_t frag[4];
+  const int gran = (g + (i >> 1) + w) & 3;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    frag[t] = *reinterpret_cast<const u32x4_t*>(&src[((4 * w + t) * 16 + i) * 16 + 4 * gran]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const mfma_h8 b = __builtin_bit_cast(mfma_h8, frag[t]);
+    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(d.a_re, b, zero, 0, 0, 0);
+    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(d.a_im, b, zero, 0, 0, 0);
+    const int rot = (t + 2 * w + (t >> 1)) & 3;
+    const int pos = (i + 4 * rot) & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const c32 y = MfmaDir<FWD>::twiddle(cr[r], ci[r], t2[r]);
+      dst[((4 * g + r) * 16 + 4 * w + t) * 16 + pos] = pack_f16(y.x, y.y);
+    }
+  }
+}
+
+// Pass 3: image `src` (rows (k2, k1), points n3) to registers: out[t][r] = X[i + 16 (4w + t) + 256 (4g + r)].
+template <bool FWD>
+__device__ __forceinline__ void mfma_pass3(const MfmaDir<FWD>& d, const unsigned* src, mfma_f4 (&xr)[4], mfma_f4 (&xi)[4],
+                                           int w, int g, int i) {
+  const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
+  u32x4_t frag[4];
+  const int gran = (g + i + (i >> 1)) & 3;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    frag[t] = *reinterpret_cast<const u32x4_t*>(&src[((4 * w + t) * 16 + i) * 16 + 4 * gran]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const mfma_h8 b = __builtin_bit_cast(mfma_h8, frag[t]);
+    xr[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d.a_re, b, zero, 0, 0, 0);
+    xi[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d.a_im, b, zero, 0, 0, 0);
+  }
+}
+
+// Filter spectra in the order the kernel's lanes consume them: 16-byte entry [d][t][tid] holds
+// H[d][k = i + 16 (4w + t) + 256 (4g + r)], r = 0..3 (tid = 64w + 16g + i). Counterpart of
+// permute_filter_layout4096 (conv1d_fullfft_l4096_thunder.cu:120-146).
+template <int UNUSED = 0>  // a template so that the header can be included from several translation units
+__global__ __launch_bounds__(256) void conv_mfma4096_filter_layout_kernel(const unsigned* __restrict__ h,
+                                                                         u32x4_t* __restrict__ hp, int D) {
+  const int tid = threadIdx.x, w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+  const long long d = blockIdx.x;
+  const unsigned* src = h + d * 4096;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = i + 16 * (4 * w + t) + 1024 * g;
+    hp[d * 1024 + t * 256 + tid] = u32x4_t{src[k], src[k + 256], src[k + 512], src[k + 768]};
+  }
+}
+
+// Signals [B][D][4096]; workgroups that share a filter are adjacent (block = d * nb + b').
+//   KIND complex  : x, y interleaved fp16 complex
+//   KIND real in  : x real fp16, y complex
+//   KIND real pair: x, y real fp16, real taps; signals (2b', 2b'+1) of filter d share one transform
+template <int KIND>
+__global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_kernel(const void* __restrict__ xv, const u32x4_t* __restrict__ hp,
+                                                                  void* __restrict__ yv, const float2* __restrict__ tw, int B,
+                                                                  int D) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + Mfma4096::IMG];
+  unsigned* const img_a = lds;
+  unsigned* const img_b = lds + Mfma4096::OUT_IMG;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+
+  const int nb = (KIND == kConvMfmaRealPair) ? (B + 1) >> 1 : B;
+  const int d = blockIdx.x / nb;
+  const int bq = blockIdx.x - d * nb;
+  const int b0 = (KIND == kConvMfmaRealPair) ? 2 * bq : bq;
+  const bool two = (KIND == kConvMfmaRealPair) && (b0 + 1 < B);
+  const long long s0 = (long long)b0 * D + d, s1 = s0 + D;
+
+  // ---- rows of the signal: lane (g, i) of wave w takes rows 4G + g, columns 64w + 4i .. 4i+3
+  u32x4_t rows[4];
+  if constexpr (KIND == kConvMfmaComplex) {
+    const u32x4_t* src = static_cast<const u32x4_t*>(xv) + s0 * 1024 + 16 * w + i;
+#pragma unroll
+    for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
+  } else {
+    const u32x2_t* src0 = static_cast<const u32x2_t*>(xv) + s0 * 1024 + 16 * w + i;
+    const u32x2_t* src1 = static_cast<const u32x2_t*>(xv) + s1 * 1024 + 16 * w + i;
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+      const u32x2_t a = __builtin_nontemporal_load(src0 + (4 * G + g) * 64);
+      u32x2_t c = {0u, 0u};
+      if (two) c = __builtin_nontemporal_load(src1 + (4 * G + g) * 64);
+      // (re, im) = (signal b0, signal b0 + 1 or zero), one dword per point
+      rows[G] = u32x4_t{(a.x & 0xffffu) | (c.x << 16), (a.x >> 16) | (c.x & 0xffff0000u),
+                        (a.y & 0xffffu) | (c.y << 16), (a.y >> 16) | (c.y & 0xffff0000u)};
+    }
+  }
+  // ---- the filter in lane order, the twiddle starts and steps, the matrix fragments
+  u32x4_t hreg[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) hreg[t] = hp[(long long)d * 1024 + t * 256 + tid];
+  const float4* ctab = reinterpret_cast<const float4*>(tw + ConvMfma4096::OFFSET);
+  c32 start_g[4], start_c[4], step_g[4], step_c[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 a = ctab[h * 256 + tid], b = ctab[512 + h * 256 + tid];
+    const float4 p = ctab[1024 + h * 4 + g], q = ctab[1032 + h * 4 + g];
+    start_g[2 * h] = make_float2(a.x, a.y);
+    start_g[2 * h + 1] = make_float2(a.z, a.w);
+    start_c[2 * h] = make_float2(b.x, b.y);
+    start_c[2 * h + 1] = make_float2(b.z, b.w);
+    step_g[2 * h] = make_float2(p.x, p.y);
+    step_g[2 * h + 1] = make_float2(p.z, p.w);
+    step_c[2 * h] = make_float2(q.x, q.y);
+    step_c[2 * h + 1] = make_float2(q.z, q.w);
+  }
+  c32 t2[4];
+  {
+    const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
+    const u32x4_t p = ftab[128], q = ftab[192];
+    t2[0] = make_float2(__uint_as_float(p.x), __uint_as_float(p.y));
+    t2[1] = make_float2(__uint_as_float(p.z), __uint_as_float(p.w));
+    t2[2] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+    t2[3] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
+  }
+  MfmaDir<true> fwd;
+  MfmaDir<false> inv;
+  fwd.init(tw, tid);
+  inv.init(tw, tid);
+
+  // ---- forward transform
+  u32x4_t packed[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned a0 = rows[0][j], a1 = rows[1][j], a2 = rows[2][j], a3 = rows[3][j];
+    auto s = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+    a0 = s[0]; a2 = s[1];
+    s = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+    a1 = s[0]; a3 = s[1];
+    s = __builtin_amdgcn_permlane16_swap(a0, a1, false, false);
+    a0 = s[0]; a1 = s[1];
+    s = __builtin_amdgcn_permlane16_swap(a2, a3, false, false);
+    a2 = s[0]; a3 = s[1];
+    packed[j] = u32x4_t{a0, a1, a2, a3};
+  }
+  mfma_pass1<true, false>(fwd, packed, start_g, step_g, img_a, w, g, i);
+  __syncthreads();
+  mfma_pass2<true>(fwd, t2, img_a, img_b, w, g, i);
+  __syncthreads();
+  mfma_f4 xr[4], xi[4];
+  mfma_pass3<true>(fwd, img_b, xr, xi, w, g, i);
+
+  // ---- product with the filter spectrum, rounded to fp16: the inverse's first-pass fragments
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned hw = hreg[t][r];
+      const float2 hf = __half22float2(*reinterpret_cast<const __half2*>(&hw));
+      const float re = xr[t][r] * hf.x - xi[t][r] * hf.y;
+      const float im = xr[t][r] * hf.y + xi[t][r] * hf.x;
+      packed[t][r] = pack_f16(re, im);
+    }
+  }
+
+  // ---- inverse transform (image a is free: every wave is past the barrier that followed its reads)
+  mfma_pass1<false, true>(inv, packed, start_c, step_c, img_a, w, g, i);
+  __syncthreads();
+  mfma_pass2<false>(inv, t2, img_a, img_b, w, g, i);
+  __syncthreads();
+  mfma_pass3<false>(inv, img_b, xr, xi, w, g, i);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k3 = 4 * g + r;
+      img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = pack_f16(xr[t][r], xi[t][r]);
+    }
+  }
+  __syncthreads();
+
+  // ---- natural order out
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
+    if constexpr (KIND == kConvMfmaRealPair) {
+      const u32x2_t y0 = {(v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16)};
+      const u32x2_t y1 = {(v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u)};
+      __builtin_nontemporal_store(y0, static_cast<u32x2_t*>(yv) + s0 * 1024 + tid + 256 * q);
+      if (two) __builtin_nontemporal_store(y1, static_cast<u32x2_t*>(yv) + s1 * 1024 + tid + 256 * q);
+    } else {
+      __builtin_nontemporal_store(v, static_cast<u32x4_t*>(yv) + s0 * 1024 + tid + 256 * q);
+    }
+  }
+}
+
+}  // namespace tfft

@@ -18,6 +18,7 @@
 
 #include "../../include/thunderfft_c.h"
 #include "conv_plans.hpp"
+#include "fft_conv_mfma.hpp"
 #include "plans.hpp"
 #include "tile_plans.hpp"
 
@@ -225,14 +226,17 @@ int tfft_initialize(int dtype, int n) {
 
   DevicePlan p;
   // n = 4096: the table is followed by the lane-ordered tables of the matrix-core kernel
-  const size_t entries = (size_t)n + (n == tfft::Mfma4096::N ? tfft::Mfma4096::TW_LANE_ORDER + tfft::Mfma4096::FRAG_TABLE : 0);
+  const size_t entries = (size_t)n + (n == tfft::Mfma4096::N ? tfft::Mfma4096::TW_LANE_ORDER + tfft::Mfma4096::FRAG_TABLE + tfft::ConvMfma4096::TABLE : 0);
   std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
     // exact reduction of the angle: j/n is a dyadic rational, evaluated in fp64 and rounded once
     const double a = -2.0 * M_PI * (double)j / (double)n;
     h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
   }
-  if (n == tfft::Mfma4096::N) tfft::mfma4096_lane_twiddles(h.data() + n);
+  if (n == tfft::Mfma4096::N) {
+    tfft::mfma4096_lane_twiddles(h.data() + n);
+    tfft::conv_mfma4096_tables(h.data() + tfft::ConvMfma4096::OFFSET);
+  }
   TFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p.tw), sizeof(float2) * entries));
   hipError_t e = hipMemcpy(p.tw, h.data(), sizeof(float2) * entries, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -457,7 +461,7 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
 static int conv_common(const char* who, int dtype, int n, int kind, tfft::ConvEntry* e) {
   if (kind < TFFT_CONV_COMPLEX || kind > TFFT_CONV_REAL_IN_OUT)
     return fail(TFFT_ERR_INVALID, "%s: unknown kind %d", who, kind);
-  if (!tfft::lookup_conv(dtype, n, kind, e))
+  if (!tfft::lookup_conv(dtype, n, kind, (int)g_opt.mode, e))
     return fail(TFFT_ERR_UNSUPPORTED, "%s: no fused convolution kernel for %s n=%d kind=%d", who, dtype_name(dtype), n,
                 kind);
   return TFFT_OK;

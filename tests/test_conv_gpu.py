@@ -138,9 +138,9 @@ def test_large_batch_linearity_and_shift():
     assert err < 2e-3, err
     yc = conv.fft_conv(x, hp, N, conv.CONV_REAL_IN)
     torch.cuda.synchronize()
-    # two instantiations of the kernel: contraction order may differ by an fp16 ulp
-    assert torch.max(torch.abs(yc[..., 0].float() - y.float())).item() <= 1e-3
-    assert torch.max(torch.abs(yc[..., 1].float())).item() < 2e-3
+    # two different kernels (one signal per transform / two): results differ by a few fp16 ulps of 1.0
+    assert torch.max(torch.abs(yc[..., 0].float() - y.float())).item() <= 4e-3
+    assert torch.max(torch.abs(yc[..., 1].float())).item() < 4e-3
 
 
 def test_errors():
