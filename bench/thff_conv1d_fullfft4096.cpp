@@ -95,6 +95,9 @@ int main(int argc, char** argv) {
   }
 
   CHECK_HIP(hipSetDevice(device));
+  // tuning knobs outside the reference's argument list
+  if (const char* e = std::getenv("TFFT_CONV_RESIDENT_PER_CU")) tfft_set_option("conv_resident_per_cu", std::atoi(e));
+  if (const char* e = std::getenv("TFFT_MODE")) tfft_set_option("mode", std::atoi(e));
   std::srand(42);
 
   const int batch_count = B * D;

@@ -29,4 +29,7 @@ struct ConvTilesEntry {
 };
 bool lookup_conv_tiles(int dtype, int n, ConvTilesEntry* out);
 
+// Tuning: workgroups per CU of the matrix-core convolution's resident grid (0: one workgroup per work item).
+void set_conv_mfma_resident_per_cu(int v);
+
 }  // namespace tfft

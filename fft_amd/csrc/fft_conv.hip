@@ -265,11 +265,29 @@ bool lookup_conv_plan(int dtype, int kind, ConvEntry* out) {
   return false;
 }
 
+// Workgroups per CU of the resident form (0: one workgroup per work item, the default: at ~190 VGPRs the
+// resident kernel fits two workgroups per CU and measured 10-15 % slower than one-shot workgroups).
+static int g_conv_mfma_resident_per_cu = 0;
+void set_conv_mfma_resident_per_cu(int v) { g_conv_mfma_resident_per_cu = v; }
+
 template <int KIND>
 void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
   const unsigned nb = (KIND == kConvMfmaRealPair) ? ((unsigned)B + 1u) / 2u : (unsigned)B;
-  fft_conv_mfma4096_kernel<KIND><<<dim3(nb * (unsigned)D), dim3(256), 0, stream>>>(x, static_cast<const u32x4_t*>(hp), y,
-                                                                                     tw, B, D);
+  const unsigned items = nb * (unsigned)D;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const int per_cu = g_conv_mfma_resident_per_cu;
+  if (per_cu > 0 && items > (unsigned)(per_cu * cus)) {
+    fft_conv_mfma4096_kernel<KIND, true><<<dim3((unsigned)(per_cu * cus)), dim3(256), 0, stream>>>(
+        x, static_cast<const u32x4_t*>(hp), y, tw, B, D);
+  } else {
+    fft_conv_mfma4096_kernel<KIND, false><<<dim3(items), dim3(256), 0, stream>>>(x, static_cast<const u32x4_t*>(hp), y, tw,
+                                                                                 B, D);
+  }
 }
 
 void launch_layout_mfma(const void* h, void* hp, int D, hipStream_t stream) {

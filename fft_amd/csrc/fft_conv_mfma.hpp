@@ -160,8 +160,10 @@ __global__ __launch_bounds__(256) void conv_mfma4096_filter_layout_kernel(const 
 //   KIND complex  : x, y interleaved fp16 complex
 //   KIND real in  : x real fp16, y complex
 //   KIND real pair: x, y real fp16, real taps; signals (2b', 2b'+1) of filter d share one transform
-template <int KIND>
-__global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_kernel(const void* __restrict__ xv, const u32x4_t* __restrict__ hp,
+// PERSIST: a resident grid; a workgroup walks work items blockIdx.x, blockIdx.x + gridDim.x, ... and
+// requests the rows of its next item as soon as the current rows are packed into fragments.
+template <int KIND, bool PERSIST>
+__global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel(const void* __restrict__ xv, const u32x4_t* __restrict__ hp,
                                                                   void* __restrict__ yv, const float2* __restrict__ tw, int B,
                                                                   int D) {
   __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + Mfma4096::IMG];
@@ -170,36 +172,53 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_kernel(const void* _
   const int tid = threadIdx.x;
   const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
 
+  // work item -> (filter d, signal b0 [and b0 + 1]); items that share a filter are adjacent
   const int nb = (KIND == kConvMfmaRealPair) ? (B + 1) >> 1 : B;
-  const int d = blockIdx.x / nb;
-  const int bq = blockIdx.x - d * nb;
-  const int b0 = (KIND == kConvMfmaRealPair) ? 2 * bq : bq;
-  const bool two = (KIND == kConvMfmaRealPair) && (b0 + 1 < B);
-  const long long s0 = (long long)b0 * D + d, s1 = s0 + D;
+  const long long items = (long long)nb * D;
+  struct Item {
+    int d;
+    bool two;
+    long long s0, s1;
+  };
+  auto locate = [&](long long idx) {
+    Item it;
+    it.d = (int)(idx / nb);
+    const int bq = (int)(idx - (long long)it.d * nb);
+    const int b0 = (KIND == kConvMfmaRealPair) ? 2 * bq : bq;
+    it.two = (KIND == kConvMfmaRealPair) && (b0 + 1 < B);
+    it.s0 = (long long)b0 * D + it.d;
+    it.s1 = it.s0 + D;
+    return it;
+  };
 
-  // ---- rows of the signal: lane (g, i) of wave w takes rows 4G + g, columns 64w + 4i .. 4i+3
+  // ---- rows of a signal: lane (g, i) of wave w takes rows 4G + g, columns 64w + 4i .. 4i+3
   u32x4_t rows[4];
-  if constexpr (KIND == kConvMfmaComplex) {
-    const u32x4_t* src = static_cast<const u32x4_t*>(xv) + s0 * 1024 + 16 * w + i;
+  auto request_rows = [&](const Item& it) {
+    if constexpr (KIND == kConvMfmaComplex) {
+      const u32x4_t* src = static_cast<const u32x4_t*>(xv) + it.s0 * 1024 + 16 * w + i;
 #pragma unroll
-    for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
-  } else {
-    const u32x2_t* src0 = static_cast<const u32x2_t*>(xv) + s0 * 1024 + 16 * w + i;
-    const u32x2_t* src1 = static_cast<const u32x2_t*>(xv) + s1 * 1024 + 16 * w + i;
+      for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
+    } else {
+      const u32x2_t* src0 = static_cast<const u32x2_t*>(xv) + it.s0 * 1024 + 16 * w + i;
+      const u32x2_t* src1 = static_cast<const u32x2_t*>(xv) + it.s1 * 1024 + 16 * w + i;
 #pragma unroll
-    for (int G = 0; G < 4; ++G) {
-      const u32x2_t a = __builtin_nontemporal_load(src0 + (4 * G + g) * 64);
-      u32x2_t c = {0u, 0u};
-      if (two) c = __builtin_nontemporal_load(src1 + (4 * G + g) * 64);
-      // (re, im) = (signal b0, signal b0 + 1 or zero), one dword per point
-      rows[G] = u32x4_t{(a.x & 0xffffu) | (c.x << 16), (a.x >> 16) | (c.x & 0xffff0000u),
-                        (a.y & 0xffffu) | (c.y << 16), (a.y >> 16) | (c.y & 0xffff0000u)};
+      for (int G = 0; G < 4; ++G) {
+        const u32x2_t a = __builtin_nontemporal_load(src0 + (4 * G + g) * 64);
+        u32x2_t c = {0u, 0u};
+        if (it.two) c = __builtin_nontemporal_load(src1 + (4 * G + g) * 64);
+        // (re, im) = (signal b0, signal b0 + 1 or zero), one dword per point
+        rows[G] = u32x4_t{(a.x & 0xffffu) | (c.x << 16), (a.x >> 16) | (c.x & 0xffff0000u),
+                          (a.y & 0xffffu) | (c.y << 16), (a.y >> 16) | (c.y & 0xffff0000u)};
+      }
     }
-  }
-  // ---- the filter in lane order, the twiddle starts and steps, the matrix fragments
-  u32x4_t hreg[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) hreg[t] = hp[(long long)d * 1024 + t * 256 + tid];
+  };
+
+  long long idx = blockIdx.x;
+  if (idx >= items) return;
+  Item cur = locate(idx);
+  request_rows(cur);
+
+  // ---- the twiddle starts and steps, the matrix fragments
   const float4* ctab = reinterpret_cast<const float4*>(tw + ConvMfma4096::OFFSET);
   c32 start_g[4], start_c[4], step_g[4], step_c[4];
 #pragma unroll
@@ -229,69 +248,87 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_kernel(const void* _
   fwd.init(tw, tid);
   inv.init(tw, tid);
 
-  // ---- forward transform
-  u32x4_t packed[4];
+  for (;;) {
+    // ---- this item's filter in lane order: it has the forward transform's time to arrive
+    u32x4_t hreg[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned a0 = rows[0][j], a1 = rows[1][j], a2 = rows[2][j], a3 = rows[3][j];
-    auto s = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
-    a0 = s[0]; a2 = s[1];
-    s = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
-    a1 = s[0]; a3 = s[1];
-    s = __builtin_amdgcn_permlane16_swap(a0, a1, false, false);
-    a0 = s[0]; a1 = s[1];
-    s = __builtin_amdgcn_permlane16_swap(a2, a3, false, false);
-    a2 = s[0]; a3 = s[1];
-    packed[j] = u32x4_t{a0, a1, a2, a3};
-  }
-  mfma_pass1<true, false>(fwd, packed, start_g, step_g, img_a, w, g, i);
-  __syncthreads();
-  mfma_pass2<true>(fwd, t2, img_a, img_b, w, g, i);
-  __syncthreads();
-  mfma_f4 xr[4], xi[4];
-  mfma_pass3<true>(fwd, img_b, xr, xi, w, g, i);
+    for (int t = 0; t < 4; ++t) hreg[t] = hp[(long long)cur.d * 1024 + t * 256 + tid];
 
-  // ---- product with the filter spectrum, rounded to fp16: the inverse's first-pass fragments
+    // ---- forward transform
+    u32x4_t packed[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned hw = hreg[t][r];
-      const float2 hf = __half22float2(*reinterpret_cast<const __half2*>(&hw));
-      const float re = xr[t][r] * hf.x - xi[t][r] * hf.y;
-      const float im = xr[t][r] * hf.y + xi[t][r] * hf.x;
-      packed[t][r] = pack_f16(re, im);
+    for (int j = 0; j < 4; ++j) {
+      unsigned a0 = rows[0][j], a1 = rows[1][j], a2 = rows[2][j], a3 = rows[3][j];
+      auto s = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+      a0 = s[0]; a2 = s[1];
+      s = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+      a1 = s[0]; a3 = s[1];
+      s = __builtin_amdgcn_permlane16_swap(a0, a1, false, false);
+      a0 = s[0]; a1 = s[1];
+      s = __builtin_amdgcn_permlane16_swap(a2, a3, false, false);
+      a2 = s[0]; a3 = s[1];
+      packed[j] = u32x4_t{a0, a1, a2, a3};
     }
-  }
+    const long long next = idx + gridDim.x;
+    const bool more = PERSIST && next < items;
+    Item nxt = cur;
+    if (more) {
+      nxt = locate(next);
+      request_rows(nxt);
+    }
+    mfma_pass1<true, false>(fwd, packed, start_g, step_g, img_a, w, g, i);
+    __syncthreads();
+    mfma_pass2<true>(fwd, t2, img_a, img_b, w, g, i);
+    __syncthreads();
+    mfma_f4 xr[4], xi[4];
+    mfma_pass3<true>(fwd, img_b, xr, xi, w, g, i);
 
-  // ---- inverse transform (image a is free: every wave is past the barrier that followed its reads)
-  mfma_pass1<false, true>(inv, packed, start_c, step_c, img_a, w, g, i);
-  __syncthreads();
-  mfma_pass2<false>(inv, t2, img_a, img_b, w, g, i);
-  __syncthreads();
-  mfma_pass3<false>(inv, img_b, xr, xi, w, g, i);
+    // ---- product with the filter spectrum, rounded to fp16: the inverse's first-pass fragments
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k3 = 4 * g + r;
-      img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = pack_f16(xr[t][r], xi[t][r]);
+      for (int r = 0; r < 4; ++r) {
+        const unsigned hw = hreg[t][r];
+        const float2 hf = __half22float2(*reinterpret_cast<const __half2*>(&hw));
+        const float re = xr[t][r] * hf.x - xi[t][r] * hf.y;
+        const float im = xr[t][r] * hf.y + xi[t][r] * hf.x;
+        packed[t][r] = pack_f16(re, im);
+      }
     }
-  }
-  __syncthreads();
 
-  // ---- natural order out
+    // ---- inverse transform (image a is free: every wave is past the barrier that followed its reads)
+    mfma_pass1<false, true>(inv, packed, start_c, step_c, img_a, w, g, i);
+    __syncthreads();
+    mfma_pass2<false>(inv, t2, img_a, img_b, w, g, i);
+    __syncthreads();
+    mfma_pass3<false>(inv, img_b, xr, xi, w, g, i);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
-    if constexpr (KIND == kConvMfmaRealPair) {
-      const u32x2_t y0 = {(v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16)};
-      const u32x2_t y1 = {(v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u)};
-      __builtin_nontemporal_store(y0, static_cast<u32x2_t*>(yv) + s0 * 1024 + tid + 256 * q);
-      if (two) __builtin_nontemporal_store(y1, static_cast<u32x2_t*>(yv) + s1 * 1024 + tid + 256 * q);
-    } else {
-      __builtin_nontemporal_store(v, static_cast<u32x4_t*>(yv) + s0 * 1024 + tid + 256 * q);
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k3 = 4 * g + r;
+        img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = pack_f16(xr[t][r], xi[t][r]);
+      }
     }
+    __syncthreads();
+
+    // ---- natural order out
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
+      if constexpr (KIND == kConvMfmaRealPair) {
+        const u32x2_t y0 = {(v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16)};
+        const u32x2_t y1 = {(v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u)};
+        __builtin_nontemporal_store(y0, static_cast<u32x2_t*>(yv) + cur.s0 * 1024 + tid + 256 * q);
+        if (cur.two) __builtin_nontemporal_store(y1, static_cast<u32x2_t*>(yv) + cur.s1 * 1024 + tid + 256 * q);
+      } else {
+        __builtin_nontemporal_store(v, static_cast<u32x4_t*>(yv) + cur.s0 * 1024 + tid + 256 * q);
+      }
+    }
+    if (!more) break;
+    __syncthreads();  // the output image is read before the next item's first pass overwrites it
+    idx = next;
+    cur = nxt;
   }
 }
 

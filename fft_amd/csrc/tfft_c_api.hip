@@ -335,6 +335,7 @@ int tfft_set_option(const char* key, long long value) {
   else if (!strcmp(key, "sync")) g_opt.sync = value;
   else if (!strcmp(key, "extra_lds")) g_opt.extra_lds = value;
   else if (!strcmp(key, "grid_blocks")) g_opt.grid_blocks = value;
+  else if (!strcmp(key, "conv_resident_per_cu")) tfft::set_conv_mfma_resident_per_cu((int)value);
   else return fail(TFFT_ERR_INVALID, "tfft_set_option: unknown key '%s'", key);
   return TFFT_OK;
 }

@@ -73,6 +73,8 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *   "grid_blocks_per_cu" : resident grid of value * CU count workgroups that walk the batch
  *                          (0 = default: one workgroup per chunk of transforms)
  *   "grid_blocks"        : resident grid of exactly value workgroups (overrides the per-CU form)
+ *   "conv_resident_per_cu": workgroups per CU of the fp16 convolution's resident grid (default 0 = one
+ *                          workgroup per signal, which measured faster)
  *   "extra_lds"          : bytes of unused dynamic LDS per workgroup, to lower occupancy
  *   "mode"               : 0 = FFT, 1 = load/store only, 2 = no LDS exchange (1 and 2 give wrong
  *                          results on purpose; they price the memory pattern and the butterflies)

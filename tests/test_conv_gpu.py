@@ -143,6 +143,24 @@ def test_large_batch_linearity_and_shift():
     assert torch.max(torch.abs(yc[..., 1].float())).item() < 4e-3
 
 
+def test_resident_form_matches_one_shot():
+    # the fp16 kernels as a resident grid (workgroups loop over signals, rows prefetched): same bits
+    B, D = 40, 60
+    x = torch.rand(B, D, N, device="cuda").to(torch.float16)
+    h = (torch.rand(D, 9, 2, device="cuda") / N).to(torch.float16)
+    h[..., 1] = 0
+    hp = conv.filter_spectra(h, N)
+    for kind in (conv.CONV_REAL_IN_OUT, conv.CONV_REAL_IN):
+        a = conv.fft_conv(x, hp, N, kind)
+        try:
+            fft_amd.set_option("conv_resident_per_cu", 2)
+            b = conv.fft_conv(x, hp, N, kind)
+        finally:
+            fft_amd.set_option("conv_resident_per_cu", 0)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), kind
+
+
 def test_errors():
     x = torch.zeros(1, 1, 1024, 2, device="cuda")
     with pytest.raises(fft_amd.ThunderFFTError) as e:
