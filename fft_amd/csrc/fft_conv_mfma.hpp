@@ -22,7 +22,7 @@ namespace tfft {
 struct ConvMfma4096 {
   // float2 entries appended after Mfma4096's tables
   static constexpr int TABLE = 2 * (512 + 512 + 8 + 8);
-  static constexpr int OFFSET = Mfma4096::N + Mfma4096::TW_LANE_ORDER + Mfma4096::FRAG_TABLE;
+  static constexpr int OFFSET = Mfma4096::N + Mfma4096::TABLES;
 };
 
 // Host side. float4 units: start_global [h][tid] (512), start_chain [h][tid] (512), step_global [h][g] (8),

@@ -44,6 +44,8 @@ struct Mfma4096 {
   static constexpr int OUT_IMG = 4096 + 64;   // natural-order output image, 4 dwords of pad per 256
   static constexpr int TW_LANE_ORDER = 4096;  // float2 entries appended to the twiddle table: pass-1 twiddles
   static constexpr int FRAG_TABLE = 1024;     // then, per direction: matrix fragments and pass-2 twiddles per lane
+  static constexpr int BF16_FRAG_TABLE = 1024;  // then, per direction: the matrix as bf16 high and low parts per lane
+  static constexpr int TABLES = TW_LANE_ORDER + FRAG_TABLE + BF16_FRAG_TABLE;
 };
 
 // Host side: the pass-1 twiddles in the order the kernel's lanes consume them. Entry
@@ -99,6 +101,39 @@ inline void mfma4096_lane_twiddles(float2* dst) {
       memcpy(base + 16 * (d * 256 + 2 * 64 + l), t2, 16);
       memcpy(base + 16 * (d * 256 + 3 * 64 + l), t2 + 4, 16);
     }
+  // bf16 storage: 16-byte entry [d*256 + q*64 + l]: q = 0, 1 the two matrices rounded to bf16, q = 2, 3 the
+  // rounding remainders (value - high part) as bf16, so that high + low carries 16 mantissa bits
+  auto bf16_rne = [](float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  };
+  auto bf16_val = [](unsigned short b) {
+    const unsigned u = (unsigned)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  unsigned char* bbase = base + 8 * Mfma4096::FRAG_TABLE;
+  for (int d = 0; d < 2; ++d)
+    for (int l = 0; l < 64; ++l) {
+      const int g = l >> 4, i = l & 15;
+      unsigned short hi[2][8], lo[2][8];
+      for (int jj = 0; jj < 4; ++jj) {
+        const double a = 2.0 * M_PI * (double)((i * (4 * g + jj)) & 15) / 16.0;
+        const float c = (float)cos(a), sn = (float)(d == 0 ? sin(a) : -sin(a));
+        const float v[2][2] = {{c, sn}, {-sn, c}};
+        for (int m = 0; m < 2; ++m)
+          for (int part = 0; part < 2; ++part) {
+            hi[m][2 * jj + part] = bf16_rne(v[m][part]);
+            lo[m][2 * jj + part] = bf16_rne(v[m][part] - bf16_val(hi[m][2 * jj + part]));
+          }
+      }
+      memcpy(bbase + 16 * (d * 256 + 0 * 64 + l), hi[0], 16);
+      memcpy(bbase + 16 * (d * 256 + 1 * 64 + l), hi[1], 16);
+      memcpy(bbase + 16 * (d * 256 + 2 * 64 + l), lo[0], 16);
+      memcpy(bbase + 16 * (d * 256 + 3 * 64 + l), lo[1], 16);
+    }
 }
 
 __device__ __forceinline__ unsigned pack_f16(float re, float im) {
@@ -106,12 +141,64 @@ __device__ __forceinline__ unsigned pack_f16(float re, float im) {
   return *reinterpret_cast<const unsigned*>(&h);
 }
 
+typedef __bf16 mfma_bf8 __attribute__((ext_vector_type(8)));
+
+// The 16-point DFT of 16 columns on the matrix cores for one 16-bit storage type: this lane's rows of
+// the real-ified matrix, and the product with a B fragment (four (re, im) pairs of one column).
+//   fp16: operands fp16, one v_mfma_f32_16x16x32_f16 per output part.
+//   bf16: operands bf16; the matrix is split into a bf16 high part and a bf16 remainder (two
+//         v_mfma_f32_16x16x32_bf16 per output part), which takes its rounding error from 2^-9 to 2^-17
+//         and leaves the data's own bf16 rounding as the only error of a pass. Intermediates in bf16
+//         keep the fp32 exponent range, so there is no overflow condition beyond the result's own.
+struct MfmaF16 {
+  u32x4_t re, im;
+  __device__ __forceinline__ void init(const float2* tw, bool fwd, int lane) {
+    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (fwd ? 0 : 256) + lane;
+    re = t[0];
+    im = t[64];
+  }
+  __device__ __forceinline__ void dft16(u32x4_t b, mfma_f4& cr, mfma_f4& ci) const {
+    const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const mfma_h8 bv = __builtin_bit_cast(mfma_h8, b);
+    cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_h8, re), bv, zero, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_h8, im), bv, zero, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned pack(float re_, float im_) { return pack_f16(re_, im_); }
+};
+
+template <bool SPLIT>
+struct MfmaBF16T {
+  u32x4_t re_hi, im_hi, re_lo, im_lo;
+  __device__ __forceinline__ void init(const float2* tw, bool fwd, int lane) {
+    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER + Mfma4096::FRAG_TABLE) +
+                       (fwd ? 0 : 256) + lane;
+    re_hi = t[0];
+    im_hi = t[64];
+    re_lo = t[128];
+    im_lo = t[192];
+  }
+  __device__ __forceinline__ void dft16(u32x4_t b, mfma_f4& cr, mfma_f4& ci) const {
+    const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const mfma_bf8 bv = __builtin_bit_cast(mfma_bf8, b);
+    cr = ci = zero;
+    if (SPLIT) {
+      cr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf8, re_lo), bv, zero, 0, 0, 0);
+      ci = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf8, im_lo), bv, zero, 0, 0, 0);
+    }
+    cr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf8, re_hi), bv, cr, 0, 0, 0);
+    ci = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf8, im_hi), bv, ci, 0, 0, 0);
+  }
+  static __device__ __forceinline__ unsigned pack(float re_, float im_) { return StoreBF16::cvt(make_float2(re_, im_)); }
+};
+using MfmaBF16 = MfmaBF16T<true>;
+using MfmaBF16Single = MfmaBF16T<false>;
+
 // DOUBLE: two LDS images (33 KiB, three barriers) instead of one (16.6 KiB, five barriers).
 // PERSIST: a resident grid; a workgroup walks transforms blockIdx.x, blockIdx.x + gridDim.x, ... and
 // requests the rows of its next transform as soon as the current rows are packed into fragments, so
 // that its HBM requests stay in flight under the three passes (16 more live VGPRs).
-template <bool FWD, bool DOUBLE, int MINW, bool PERSIST = false>
-__global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4_t* __restrict__ in,
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false>
+__global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* __restrict__ in,
                                                                      u32x4_t* __restrict__ out,
                                                                      const float2* __restrict__ tw, long long batch) {
   __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + (DOUBLE ? Mfma4096::IMG : 0)];
@@ -137,10 +224,9 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4
   float4 t1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) t1[e] = tw1[e * 256];
-  const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) +
-                        (FWD ? 0 : 256) + (tid & 63);
-  const mfma_h8 a_re = __builtin_bit_cast(mfma_h8, ftab[0]);
-  const mfma_h8 a_im = __builtin_bit_cast(mfma_h8, ftab[64]);
+  const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
+  T16 mat;
+  mat.init(tw, FWD, tid & 63);
   c32 t2[4];
   {
     const u32x4_t p = ftab[128], q = ftab[192];
@@ -155,8 +241,6 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4
     if (FWD) return make_float2(re * t.x - im * t.y, re * t.y + im * t.x);
     return make_float2(re * t.x + im * t.y, im * t.x - re * t.y);
   };
-  const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
-
   for (;;) {
   // ---- pass 1: transpose rows <-> lane groups, then 16 columns {64w + 4i + j} per j
   u32x4_t packed[4];
@@ -177,9 +261,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4
   if (PERSIST && next < batch) request_rows(next);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const mfma_h8 b = __builtin_bit_cast(mfma_h8, packed[j]);
-    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_re, b, zero, 0, 0, 0);
-    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_im, b, zero, 0, 0, 0);
+    mfma_f4 cr, ci;
+    mat.dft16(packed[j], cr, ci);
     // lane holds Y1[k1 = 4g + r][n2 = 4w + (i >> 2)][n3 = 4 (i & 3) + j]; image 2 row = (k1, n3), point n2
     const int n2 = 4 * w + (i >> 2);
     const int rot = (2 * (i & 3) + (j >> 1) + g) & 3;
@@ -190,7 +273,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4
       const c32 t = (r & 1) ? make_float2(tt.z, tt.w) : make_float2(tt.x, tt.y);
       const c32 y = twiddle(cr[r], ci[r], t);
       const int row = (4 * g + r) * 16 + 4 * (i & 3) + j;
-      img_a[row * 16 + pos] = pack_f16(y.x, y.y);
+      img_a[row * 16 + pos] = T16::pack(y.x, y.y);
     }
   }
   __syncthreads();
@@ -207,9 +290,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4
   if (!DOUBLE) __syncthreads();
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const mfma_h8 b = __builtin_bit_cast(mfma_h8, frag[t]);
-    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_re, b, zero, 0, 0, 0);
-    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_im, b, zero, 0, 0, 0);
+    mfma_f4 cr, ci;
+    mat.dft16(frag[t], cr, ci);
     // lane holds Y2[k1 = 4w + t][k2 = 4g + r][n3 = i]; image 3 row = (k2, k1), point n3
     const int rot = (t + 2 * w + (t >> 1)) & 3;
     const int pos = (i + 4 * rot) & 15;
@@ -217,7 +299,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4
     for (int r = 0; r < 4; ++r) {
       const c32 y = twiddle(cr[r], ci[r], t2[r]);
       const int row = (4 * g + r) * 16 + 4 * w + t;
-      img_b[row * 16 + pos] = pack_f16(y.x, y.y);
+      img_b[row * 16 + pos] = T16::pack(y.x, y.y);
     }
   }
   __syncthreads();
@@ -233,14 +315,13 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_f16_kernel(const u32x4
   if (!DOUBLE) __syncthreads();
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const mfma_h8 b = __builtin_bit_cast(mfma_h8, frag[t]);
-    const mfma_f4 cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_re, b, zero, 0, 0, 0);
-    const mfma_f4 ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_im, b, zero, 0, 0, 0);
+    mfma_f4 cr, ci;
+    mat.dft16(frag[t], cr, ci);
     // lane holds X[k = i + 16 (4w + t) + 256 (4g + r)]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k3 = 4 * g + r;
-      img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = pack_f16(cr[r], ci[r]);
+      img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = T16::pack(cr[r], ci[r]);
     }
   }
   __syncthreads();

@@ -9,7 +9,17 @@ bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
     case 512: return entry_for<Plan512, StoreBF16, false>(forward, mode, out);
     case 1024: return entry_for<Plan1024, StoreBF16, false>(forward, mode, out);
     case 2048: return entry_for<Plan2048, StoreBF16, false>(forward, mode, out);
-    case 4096: return entry_for<Plan4096, StoreBF16, true, Plan4096Mfma, Plan4096ResidentSplit>(forward, mode, out);
+    case 4096:
+      // Default: three passes on the matrix cores with bf16 operands, resident prefetching grid
+      // (rel-L2 3.5e-3 against the 1e-2 gate; 68 % of HBM). Mode 8: the same with the DFT matrix split
+      // into bf16 high and low parts (2.9e-3, 62 %); 6: split matrix, one workgroup per transform;
+      // 3: the fp32 VALU kernel (1.7e-3, 56 %).
+      if (mode == 0) { *out = forward ? make_mfma_entry<MfmaBF16Single, true, true, 4, true>() : make_mfma_entry<MfmaBF16Single, false, true, 4, true>(); return true; }
+      if (mode == 8) { *out = forward ? make_mfma_entry<MfmaBF16, true, true, 4, true>() : make_mfma_entry<MfmaBF16, false, true, 4, true>(); return true; }
+      if (mode == 6) { *out = forward ? make_mfma_entry<MfmaBF16, true, true, 4>() : make_mfma_entry<MfmaBF16, false, true, 4>(); return true; }
+      if (mode == 3) mode = 0;
+      else if (mode != 1 && mode != 2) return false;
+      return entry_for<Plan4096, StoreBF16, true>(forward, mode, out);
     case 8192: return entry_for<Plan8192, StoreBF16, false>(forward, mode, out);
     case 16384: return entry_for<Plan16384, StoreBF16, false>(forward, mode, out);
     default: return false;

@@ -14,10 +14,10 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
       // (fft_mfma_kernel.hpp). Mode 3: the VALU kernel; 4: VALU with the middle pass on the matrix
       // cores; 5 / 6: matrix cores, one workgroup per transform, one / two LDS images; 7: resident with
       // one LDS image; 9: VALU kernel as a resident prefetching grid.
-      if (mode == 0) { *out = forward ? make_mfma_entry<true, true, 4, true>() : make_mfma_entry<false, true, 4, true>(); return true; }
-      if (mode == 5) { *out = forward ? make_mfma_entry<true, false, 4>() : make_mfma_entry<false, false, 4>(); return true; }
-      if (mode == 6) { *out = forward ? make_mfma_entry<true, true, 4>() : make_mfma_entry<false, true, 4>(); return true; }
-      if (mode == 7) { *out = forward ? make_mfma_entry<true, false, 4, true>() : make_mfma_entry<false, false, 4, true>(); return true; }
+      if (mode == 0) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4, true>() : make_mfma_entry<MfmaF16, false, true, 4, true>(); return true; }
+      if (mode == 5) { *out = forward ? make_mfma_entry<MfmaF16, true, false, 4>() : make_mfma_entry<MfmaF16, false, false, 4>(); return true; }
+      if (mode == 6) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4>() : make_mfma_entry<MfmaF16, false, true, 4>(); return true; }
+      if (mode == 7) { *out = forward ? make_mfma_entry<MfmaF16, true, false, 4, true>() : make_mfma_entry<MfmaF16, false, false, 4, true>(); return true; }
       if (mode == 3) mode = 0;
       else if (mode == 4) mode = 3;
       else if (mode == 9) mode = 4;

@@ -121,22 +121,22 @@ KernelEntry make_entry() {
 }
 
 // Matrix-core kernel of fft_mfma_kernel.hpp as a table entry (one transform per workgroup).
-template <bool FWD, bool DOUBLE, int MINW, bool PERSIST>
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST>
 void launch_mfma4096(const void* in, void* out, const float2* tw, long long batch, long long nchunks, unsigned grid,
                      unsigned extra_lds, hipStream_t stream) {
   (void)nchunks;
   (void)extra_lds;
   // one-shot: one workgroup per transform; resident: the caller's grid (workgroups per CU x CUs)
   const unsigned blocks = PERSIST ? grid : (unsigned)batch;
-  fft_mfma4096_f16_kernel<FWD, DOUBLE, MINW, PERSIST><<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(
+  fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST><<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(
       static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch);
 }
 
-template <bool FWD, bool DOUBLE, int MINW, bool PERSIST = false>
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false>
 KernelEntry make_mfma_entry() {
   KernelEntry e;
-  e.fn = reinterpret_cast<const void*>(&fft_mfma4096_f16_kernel<FWD, DOUBLE, MINW, PERSIST>);
-  e.launch = &launch_mfma4096<FWD, DOUBLE, MINW, PERSIST>;
+  e.fn = reinterpret_cast<const void*>(&fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST>);
+  e.launch = &launch_mfma4096<T16, FWD, DOUBLE, MINW, PERSIST>;
   e.n = Mfma4096::N;
   e.threads = Mfma4096::WG;
   e.tpb = 1;

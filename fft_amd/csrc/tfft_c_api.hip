@@ -226,7 +226,7 @@ int tfft_initialize(int dtype, int n) {
 
   DevicePlan p;
   // n = 4096: the table is followed by the lane-ordered tables of the matrix-core kernel
-  const size_t entries = (size_t)n + (n == tfft::Mfma4096::N ? tfft::Mfma4096::TW_LANE_ORDER + tfft::Mfma4096::FRAG_TABLE + tfft::ConvMfma4096::TABLE : 0);
+  const size_t entries = (size_t)n + (n == tfft::Mfma4096::N ? tfft::Mfma4096::TABLES + tfft::ConvMfma4096::TABLE : 0);
   std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
     // exact reduction of the angle: j/n is a dyadic rational, evaluated in fp64 and rounded once

@@ -227,6 +227,28 @@ def test_fp16_4096_plans_vs_oracle(oracle_mod, mode, forward):
     assert worst <= TOL["fp16"], worst
 
 
+@pytest.mark.parametrize("mode", [0, 3, 6, 8])
+@pytest.mark.parametrize("forward", (True, False))
+def test_bf16_4096_plans_vs_oracle(oracle_mod, mode, forward):
+    """bf16 storage, N = 4096. Mode 0 (default): matrix cores with bf16 operands; modes 6 and 8: the DFT
+    matrix split into bf16 high and low parts; mode 3: the fp32 VALU kernel. Unscaled inputs: bf16
+    intermediates keep the fp32 range."""
+    n = 4096
+    batch = 2500 if mode in (0, 8) else 37
+    x = synth.uniform_complex(batch, n, seed=40 + mode)
+    try:
+        fft_amd.set_option("mode", mode)
+        got, stored = run(x, "bf16", forward)
+    finally:
+        fft_amd.set_option("mode", 0)
+    ref = oracle_mod.fft(stored, forward)
+    err = oracle_mod.rel_l2(got, ref)
+    print(f"bf16 mode={mode} forward={forward} rel_l2={err:.3e}")
+    assert err <= TOL["bf16"], f"mode={mode} forward={forward} rel_l2={err:.3e}"
+    worst = max(oracle_mod.rel_l2(got[b], ref[b]) for b in range(batch))
+    assert worst <= TOL["bf16"], worst
+
+
 def test_fp16_4096_in_place_and_small_batches(oracle_mod):
     # the default fp16 kernel is a resident grid: in place, and batches smaller than the grid
     n = 4096
