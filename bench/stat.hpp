@@ -49,11 +49,19 @@ inline void print_csv() {
 }
 
 inline void print_ndjson() {
+  // JSON has no NaN: figures that were not measured (compute_ms of a comparator row, an error without a
+  // comparator) are written as null
+  auto num = [](double v, const char* fmt) {
+    char buf[64];
+    if (v != v) return std::string("null");
+    std::snprintf(buf, sizeof buf, fmt, v);
+    return std::string(buf);
+  };
   for (const auto& s : rows())
-    std::printf("{\"type\":\"%s\",\"N\":%u,\"radix\":\"%s\",\"B\":%lld,\"max_abs_err\":%.6e,\"compute_ms\":%.6f,\"e2e_ms\":%.6f,"
+    std::printf("{\"type\":\"%s\",\"N\":%u,\"radix\":\"%s\",\"B\":%lld,\"max_abs_err\":%s,\"compute_ms\":%s,\"e2e_ms\":%.6f,"
                 "\"gflops\":%.3f,\"gbps\":%.3f,\"hbm_frac\":%.5f}\n",
-                s.type.c_str(), s.N, s.radix.c_str(), s.B, s.max_abs_err, s.compute_ms, s.e2e_ms, s.gflops, s.gbps,
-                s.hbm_frac);
+                s.type.c_str(), s.N, s.radix.c_str(), s.B, num(s.max_abs_err, "%.6e").c_str(),
+                num(s.compute_ms, "%.6f").c_str(), s.e2e_ms, s.gflops, s.gbps, s.hbm_frac);
 }
 
 }  // namespace stat
