@@ -139,6 +139,11 @@ bool lookup(int dtype, int n, bool forward, int mode, tfft::KernelEntry* e) {
   }
 }
 
+Options options_snapshot() {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return g_opt;
+}
+
 const char* dtype_name(int dtype) {
   switch (dtype) {
     case TFFT_F32: return "fp32";
@@ -417,7 +422,7 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
     return fail(TFFT_ERR_INVALID, "tfft_exec_c2c: buffers must be 16-byte aligned");
   if (dtype == TFFT_F32 && n > kMaxLdsN) {
     const int rc = exec_big(n, forward, d_in, d_out, batch, static_cast<hipStream_t>(stream));
-    if (rc == TFFT_OK && g_opt.sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (rc == TFFT_OK && options_snapshot().sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return rc;
   }
   Options opt;
@@ -462,7 +467,7 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
 static int conv_common(const char* who, int dtype, int n, int kind, tfft::ConvEntry* e) {
   if (kind < TFFT_CONV_COMPLEX || kind > TFFT_CONV_REAL_IN_OUT)
     return fail(TFFT_ERR_INVALID, "%s: unknown kind %d", who, kind);
-  if (!tfft::lookup_conv(dtype, n, kind, (int)g_opt.mode, e))
+  if (!tfft::lookup_conv(dtype, n, kind, (int)options_snapshot().mode, e))
     return fail(TFFT_ERR_UNSUPPORTED, "%s: no fused convolution kernel for %s n=%d kind=%d", who, dtype_name(dtype), n,
                 kind);
   return TFFT_OK;
@@ -503,7 +508,7 @@ int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_
   }
   e.launch(d_x, d_h_perm, d_y, plan.tw, B, D, static_cast<hipStream_t>(stream));
   TFFT_HIP(hipGetLastError());
-  if (g_opt.sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  if (options_snapshot().sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return TFFT_OK;
 }
 
@@ -532,7 +537,7 @@ int tfft_conv_tiles_exec(int dtype, int n, const void* d_in, const void* d_hf, v
   }
   e.launch(d_in, d_hf, d_out, plan.tw, input_len, output_len, valid, static_cast<hipStream_t>(stream));
   TFFT_HIP(hipGetLastError());
-  if (g_opt.sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  if (options_snapshot().sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return TFFT_OK;
 }
 
