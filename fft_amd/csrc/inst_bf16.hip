@@ -1,14 +1,16 @@
 // bf16 storage (fp32 arithmetic), every length.
 #include "inst_common.hpp"
 namespace tfft {
+// 16-bit storage halves the bytes per workgroup; where the A/B of the fp32 plans came out the other way
+// (N = 1024: three passes of 16 points per thread; N = 8192: split exchange) the default is swapped.
 bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
   switch (n) {
-    case 64: return entry_for<Plan64, StoreBF16, false>(forward, mode, out);
-    case 128: return entry_for<Plan128, StoreBF16, false>(forward, mode, out);
-    case 256: return entry_for<Plan256, StoreBF16, false>(forward, mode, out);
-    case 512: return entry_for<Plan512, StoreBF16, false>(forward, mode, out);
-    case 1024: return entry_for<Plan1024, StoreBF16, false>(forward, mode, out);
-    case 2048: return entry_for<Plan2048, StoreBF16, false>(forward, mode, out);
+    case 64: return entry_for<Plan64, StoreBF16, false, Plan64Alt>(forward, mode, out);
+    case 128: return entry_for<Plan128, StoreBF16, false, Plan128Alt>(forward, mode, out);
+    case 256: return entry_for<Plan256, StoreBF16, false, Plan256Alt>(forward, mode, out);
+    case 512: return entry_for<Plan512, StoreBF16, false, Plan512Alt>(forward, mode, out);
+    case 1024: return entry_for<Plan1024Alt, StoreBF16, false, Plan1024>(forward, mode, out);
+    case 2048: return entry_for<Plan2048, StoreBF16, false, Plan2048Alt>(forward, mode, out);
     case 4096:
       // Default: three passes on the matrix cores with bf16 operands, resident prefetching grid
       // (rel-L2 3.5e-3 against the 1e-2 gate; 68 % of HBM). Mode 8: the same with the DFT matrix split
@@ -20,8 +22,8 @@ bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
       if (mode == 3) mode = 0;
       else if (mode != 1 && mode != 2) return false;
       return entry_for<Plan4096, StoreBF16, true>(forward, mode, out);
-    case 8192: return entry_for<Plan8192, StoreBF16, false>(forward, mode, out);
-    case 16384: return entry_for<Plan16384, StoreBF16, false>(forward, mode, out);
+    case 8192: return entry_for<Plan8192Alt, StoreBF16, false, Plan8192>(forward, mode, out);
+    case 16384: return entry_for<Plan16384, StoreBF16, false, Plan16384Alt>(forward, mode, out);
     default: return false;
   }
 }

@@ -1,14 +1,16 @@
 // fp16 storage (fp32 arithmetic), every length.
 #include "inst_common.hpp"
 namespace tfft {
+// 16-bit storage halves the bytes per workgroup; where the A/B of the fp32 plans came out the other way
+// (N = 1024: three passes of 16 points per thread; N = 8192: split exchange) the default is swapped.
 bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
   switch (n) {
-    case 64: return entry_for<Plan64, StoreF16, false>(forward, mode, out);
-    case 128: return entry_for<Plan128, StoreF16, false>(forward, mode, out);
-    case 256: return entry_for<Plan256, StoreF16, false>(forward, mode, out);
-    case 512: return entry_for<Plan512, StoreF16, false>(forward, mode, out);
-    case 1024: return entry_for<Plan1024, StoreF16, false>(forward, mode, out);
-    case 2048: return entry_for<Plan2048, StoreF16, false>(forward, mode, out);
+    case 64: return entry_for<Plan64, StoreF16, false, Plan64Alt>(forward, mode, out);
+    case 128: return entry_for<Plan128, StoreF16, false, Plan128Alt>(forward, mode, out);
+    case 256: return entry_for<Plan256, StoreF16, false, Plan256Alt>(forward, mode, out);
+    case 512: return entry_for<Plan512, StoreF16, false, Plan512Alt>(forward, mode, out);
+    case 1024: return entry_for<Plan1024Alt, StoreF16, false, Plan1024>(forward, mode, out);
+    case 2048: return entry_for<Plan2048, StoreF16, false, Plan2048Alt>(forward, mode, out);
     case 4096:
       // Default: all three passes on the matrix cores, resident grid with row prefetch, two LDS images
       // (fft_mfma_kernel.hpp). Mode 3: the VALU kernel; 4: VALU with the middle pass on the matrix
@@ -23,8 +25,8 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
       else if (mode == 9) mode = 4;
       else if (mode != 1 && mode != 2) return false;
       return entry_for<Plan4096, StoreF16, true, Plan4096Mfma, Plan4096ResidentSplit>(forward, mode, out);
-    case 8192: return entry_for<Plan8192, StoreF16, false>(forward, mode, out);
-    case 16384: return entry_for<Plan16384, StoreF16, false>(forward, mode, out);
+    case 8192: return entry_for<Plan8192Alt, StoreF16, false, Plan8192>(forward, mode, out);
+    case 16384: return entry_for<Plan16384, StoreF16, false, Plan16384Alt>(forward, mode, out);
     default: return false;
   }
 }
