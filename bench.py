@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--in-place", action="store_true", help="transform the buffer in place (the reference bench protocol) instead of x -> y")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("fp32", "fp16", "bf16"), default="fp32",
+                    help="storage type; fp32 is the headline configuration, fp16 / bf16 the 16-bit one (8 B per point)")
     args = ap.parse_args()
     args.out_of_place = not args.in_place
 
@@ -115,13 +117,16 @@ def main():
     # synthetic input, uniform(-1, 1), generated on the device (values do not affect timing)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.rand(batch, n, 2, device=dev, generator=g) * 2 - 1
+    if args.dtype != "fp32":
+        # 16-bit storage: inputs scaled by 1/sqrt(N) as the reference does (sample/bench/main.cu:36)
+        x = (x * float(n) ** -0.5).to(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
     # An unnormalised forward FFT grows random data by sqrt(N) per pass. In place, start low enough
     # (an exact power of two, mantissas untouched) that up to RESCALE_EVERY passes stay finite.
     RESCALE_EVERY = 32
     if not args.out_of_place:
         x.mul_(float(n) ** (-min(args.steps + args.warmup, RESCALE_EVERY) / 4.0))
     y = torch.empty_like(x) if args.out_of_place else x
-    fft_amd.ThunderFFTInitialize("fp32", n)
+    fft_amd.ThunderFFTInitialize(args.dtype, n)
     stream = torch.cuda.current_stream(dev)
 
     def step():
@@ -159,13 +164,13 @@ def main():
     wall, kernel_ms = sharding.max_over_ranks([wall, kernel_ms], dist, dev)
 
     ms_per_step = wall / args.steps * 1e3
-    bytes_per_launch = BYTES_PER_POINT * n * batch
+    bytes_per_launch = (BYTES_PER_POINT if args.dtype == "fp32" else BYTES_PER_POINT // 2) * n * batch
     achieved = bytes_per_launch / (kernel_ms * 1e-3) * 1e-9
 
     if rank == 0:
-        info = fft_amd.plan_info("fp32", n)
+        info = fft_amd.plan_info(args.dtype, n)
         line = {
-            "metric": "batched 1D C2C FFT GFLOP/s (5NlogN) + % HBM roofline, N=4096 fp32",
+            "metric": f"batched 1D C2C FFT GFLOP/s (5NlogN) + % HBM roofline, N={n} {args.dtype}",
             "value": round(sharding.aggregate_gflops(n, batch, world, ms_per_step * 1e-3), 1),
             "unit": "GFLOP/s",
             "n_gpus": world,
@@ -175,10 +180,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            # fp32 storage: fp32 VALU arithmetic; 16-bit storage at N = 4096: 16-bit matrix-core operands, fp32 accumulation
+            "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.dtype],
             "data": "synthetic",
             "config": {
-                "workload": f"batched 1D C2C FFT N={n} batch={batch} per GPU fp32, "
+                "workload": f"batched 1D C2C FFT N={n} batch={batch} per GPU {args.dtype}, "
                             f"{'out of place' if args.out_of_place else 'in place'}, forward",
                 "points_per_gpu": n * batch,
                 "radix": "x".join(str(r) for r in info["radix"]),
@@ -190,8 +196,11 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": recorded_traffic(f"fft_lds_kernel_f32_n{n}_b{batch}"),
-                "kernel": f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>",
+                "traffic": recorded_traffic(f"fft_lds_kernel_f32_n{n}_b{batch}") if args.dtype == "fp32"
+                else recorded_traffic(f"fft_kernel_{args.dtype}_n{n}_b{batch}"),
+                "kernel": f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>" if args.dtype == "fp32"
+                else (f"tfft::fft_mfma4096_kernel<{args.dtype}, forward>" if n == 4096
+                      else f"tfft::fft_lds_kernel<Plan{n}, {args.dtype} storage, forward>"),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },
@@ -200,7 +209,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(line), flush=True)
 
-    fft_amd.ThunderFFTFinalize("fp32")
+    fft_amd.ThunderFFTFinalize(args.dtype)
     if dist:
         dist.destroy_process_group()
 
