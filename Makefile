@@ -18,7 +18,7 @@ KERNEL_HDRS := $(wildcard $(CSRC)/*.hpp) include/thunderfft_c.h
 LIB        := $(LIBDIR)/libthunderfft_hip.so
 ORACLE     := oracle/liboracle_dft.so
 BENCH      := bench/tfft_bench
-CONVBENCH  := bench/thff_conv1d_fullfft4096 bench/thff_conv1d
+CONVBENCH  := bench/thff_conv1d_fullfft4096 bench/thff_conv1d bench/thff_fft
 
 .PHONY: all lib oracle bench examples clean
 all: lib oracle bench examples
@@ -43,6 +43,10 @@ $(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh 
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 bench/thff_conv1d%: bench/thff_conv1d%.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
+	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+bench/thff_fft: bench/thff_fft.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 

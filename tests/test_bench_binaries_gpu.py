@@ -54,6 +54,18 @@ def test_tiled_conv_cli_and_validation(input_len, filter_len):
     assert m and float(m.group(1)) < 2e-3, out
 
 
+def test_fft_sample_report():
+    # the reference's minimal sample (sample/fft1d/main.cu:74-163): tones on bins 1 + b and 7
+    out = run("thff_fft")
+    m = re.search(r"Compare vs hipFFT\s*: L2_rel=([0-9.eE+-]+)\s+Linf_rel=([0-9.eE+-]+)", out)
+    assert m and float(m.group(1)) < 1e-5 and float(m.group(2)) < 1e-5, out
+    assert re.search(r"ThunderFFT avg time : [0-9.]+ ms", out) and "Checksum(ThunderFFT):" in out
+    # batch 0: amplitude 0.5 on bin 1 and 0.1 on bin 7, times N = 64
+    k1 = re.search(r"k=\s*1\s+TF=\(([-0-9.]+), ([-0-9.]+)\)", out)
+    k7 = re.search(r"k=\s*7\s+TF=\(([-0-9.]+), ([-0-9.]+)\)", out)
+    assert abs(float(k1.group(1)) - 32.0) < 1e-3 and abs(float(k7.group(1)) - 6.4) < 1e-3, out
+
+
 def test_tfft_bench_sinks():
     out = run("tfft_bench", "--n", "256,4096", "--points", 1 << 22, "--runs", 2, "--ndjson", "--inside-repeats", 4)
     rows = [json.loads(line) for line in out.splitlines() if line.startswith("{")]
