@@ -271,6 +271,37 @@ def test_resident_grid_matches_one_shot():
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("n", [64, 512, 4096, 16384, 1 << 16])
+def test_canary_and_determinism(n, kind):
+    """Out-of-bounds and race check without a device sanitizer: guard bands on both sides of the input
+    and output stay untouched, and two runs give the same bits."""
+    if kind != "fp32" and n > 16384:
+        pytest.skip("multi-pass lengths are fp32 only")
+    batch = 2 * max(1, 8192 // n) + 1
+    guard = 4096
+    dt = TORCH_DT[kind]
+    x = synth.uniform_complex(batch, n, seed=n) / np.sqrt(n)
+    d_x = to_device(x.astype(np.complex64), kind)
+    buf_in = torch.full((guard + batch * n * 2 + guard,), 7.0, device="cuda", dtype=dt)
+    buf_out = torch.full((guard + batch * n * 2 + guard,), -3.0, device="cuda", dtype=dt)
+    buf_in[guard:guard + batch * n * 2] = d_x.reshape(-1)
+    v_in = buf_in[guard:guard + batch * n * 2].view(batch, n, 2)
+    v_out = buf_out[guard:guard + batch * n * 2].view(batch, n, 2)
+    fft_amd.ThunderFFTInitialize(kind, n)
+    fft_amd.ThunderFFT_global(v_in, v_out, batch, n, True)
+    torch.cuda.synchronize()
+    first = v_out.clone()
+    fft_amd.ThunderFFT_global(v_in, v_out, batch, n, True)
+    torch.cuda.synchronize()
+    assert torch.equal(first.view(torch.int16 if kind != "fp32" else torch.int32),
+                       v_out.view(torch.int16 if kind != "fp32" else torch.int32))
+    assert torch.all(buf_out[:guard] == -3.0) and torch.all(buf_out[-guard:] == -3.0)
+    assert torch.all(buf_in[:guard] == 7.0) and torch.all(buf_in[-guard:] == 7.0)
+    assert torch.equal(v_in, d_x)
+    assert torch.all(torch.isfinite(v_out.float()))
+
+
 def test_linearity():
     n, batch = 2048, 33
     a = synth.uniform_complex(batch, n, seed=1)
