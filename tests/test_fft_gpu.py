@@ -302,6 +302,28 @@ def test_canary_and_determinism(n, kind):
     assert torch.all(torch.isfinite(v_out.float()))
 
 
+@pytest.mark.parametrize("kind,n", [("fp32", 4096), ("fp32", 1024), ("fp16", 4096), ("bf16", 4096)])
+def test_hip_graph_capture(kind, n):
+    """tfft_exec_c2c for one-kernel lengths makes no allocation and no synchronisation, so it can be
+    captured into a HIP graph and replayed."""
+    batch = 300
+    x = (synth.uniform_complex(batch, n, seed=3) / np.sqrt(n)).astype(np.complex64)
+    d_in = to_device(x, kind)
+    eager = torch.empty_like(d_in)
+    fft_amd.ThunderFFTInitialize(kind, n)
+    fft_amd.ThunderFFT_global(d_in, eager, batch, n, True)
+    torch.cuda.synchronize()
+    out = torch.zeros_like(d_in)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fft_amd.ThunderFFT_global(d_in, out, batch, n, True)  # on the capture stream (torch's current stream)
+    for _ in range(2):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+
+
 def test_linearity():
     n, batch = 2048, 33
     a = synth.uniform_complex(batch, n, seed=1)
