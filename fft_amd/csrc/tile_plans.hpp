@@ -10,7 +10,7 @@ using Tile64 = TilePlan<64, 16, 16, 4, 128, 5, 1, 4, kFlagSplit>;
 using Tile128 = TilePlan<128, 16, 16, 8, 64, 5, 1, 4, kFlagSplit>;
 using Tile256 = TilePlan<256, 16, 16, 16, 32, 5, 1, 4, kFlagSplit>;
 using Tile512 = TilePlan<512, 32, 16, 32, 16, 5, 1, 3, kFlagSplit>;
-using Tile1024 = TilePlan<1024, 32, 32, 32, 16, 5, 1, 4, kFlagSplit>;
+using Tile1024 = TilePlan<1024, 32, 32, 32, 16, 5, 1, 3, kFlagSplit>;
 
 struct TileEntry {
   void (*launch)(const TileArgs& args, hipStream_t stream);
