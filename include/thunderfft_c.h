@@ -76,8 +76,15 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *   "conv_resident_per_cu": workgroups per CU of the fp16 convolution's resident grid (default 0 = one
  *                          workgroup per signal, which measured faster)
  *   "extra_lds"          : bytes of unused dynamic LDS per workgroup, to lower occupancy
- *   "mode"               : 0 = FFT, 1 = load/store only, 2 = no LDS exchange (1 and 2 give wrong
- *                          results on purpose; they price the memory pattern and the butterflies)
+ *   "grid_blocks_per_cu" also sizes the grid of kernels that are resident by default (16-bit storage,
+ *                          n = 4096: three workgroups per CU).
+ *   "mode"               : 0 = default kernel; 1 = load/store only, 2 = no LDS exchange (both give wrong
+ *                          results on purpose; they price the memory pattern and the butterflies);
+ *                          3 and up = the alternative kernels of a (dtype, n) kept for A/B timing (another
+ *                          factorisation or workgroup size; for 16-bit storage at n = 4096, mode 3 is the
+ *                          fp32-VALU kernel and 5-8 other forms of the matrix-core kernel). A mode a length
+ *                          does not have returns TFFT_ERR_UNSUPPORTED. For the convolution entry points
+ *                          mode 3 selects the fp32-VALU kernels for fp16 storage.
  *   "sync"               : 1 = synchronise the stream after every launch like the reference */
 int tfft_set_option(const char* key, long long value);
 

@@ -1,6 +1,6 @@
 """LDS bank-conflict model for the in-LDS exchange stages of the batched FFT kernels.
 
-Mirrors the index arithmetic of fft_amd/csrc/fft_kernels.hip (first / middle / last pass
+Mirrors the index arithmetic of fft_amd/csrc/fft_lds_kernel.hpp (first / middle / last pass
 butterfly -> logical exchange index -> padded physical index) and prices every
 ds_write_b64 / ds_read_b64 wave-instruction with the gfx950 banking rules:
 
