@@ -1,4 +1,4 @@
-// N = 4096, fp16 storage: all three radix-16 passes on the matrix cores.
+// 16-bit storage, N = 256 ... 4096: the passes of the transform on the matrix cores.
 //
 // The reference computes its transforms as tensor-core products of small DFT matrices with
 // fragments of the data (thunderfft/include/thunderfft/detail/kernel/unit_kernel_fp16.cuh:97-238,
@@ -25,6 +25,13 @@
 // Data is rounded to fp16 between passes (the storage type's own precision); twiddles and
 // accumulation are fp32. Intermediate values must fit fp16, i.e. N * max|x| < 65504 -- the bound
 // that also keeps the fp16 result finite.
+//
+// N = 256 R1 with R1 = 1, 2, 4, 8: a workgroup takes 16 / R1 whole transforms (the same 4096 points,
+// 16 rows of 256) and the first pass multiplies by the block-diagonal matrix I_(16/R1) (x) DFT_R1 -- a
+// radix-R1 pass over the rows of each transform, at the matrix-core cost of the radix-16 one -- followed
+// by the twiddle W_N^(k1 (16 n2 + n3)); passes 2 and 3 are the same 256-point transforms. Row s of the
+// pass-1 result is sub-transform (transform s / R1, k1 = s mod R1) and output k = k1 + R1 (k2 + 16 k3).
+// R1 = 1 needs no first pass: the transposed rows are the pass-2 image.
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -45,12 +52,13 @@ struct Mfma4096 {
   static constexpr int TW_LANE_ORDER = 4096;  // float2 entries appended to the twiddle table: pass-1 twiddles
   static constexpr int FRAG_TABLE = 1024;     // then, per direction: matrix fragments and pass-2 twiddles per lane
   static constexpr int BF16_FRAG_TABLE = 1024;  // then, per direction: the matrix as bf16 high and low parts per lane
-  static constexpr int TABLES = TW_LANE_ORDER + FRAG_TABLE + BF16_FRAG_TABLE;
+  static constexpr int P1_TABLE = 512;  // then, per storage type and direction: the pass-1 matrix of N < 4096 per lane
+  static constexpr int TABLES = TW_LANE_ORDER + FRAG_TABLE + BF16_FRAG_TABLE + 2 * P1_TABLE;
 };
 
 // Host side: the pass-1 twiddles in the order the kernel's lanes consume them. Entry
-// [(j*2 + rp) * 256 + tid] holds the float4 { W^(k1 c), W^((k1+1) c) } with tid = 64 w + 16 g + i,
-// k1 = 4 g + 2 rp, c = 64 w + 4 i + j, W = exp(-2 pi i / 4096).
+// [(j*2 + rp) * 256 + tid] holds the float4 { W^(k1 c), W^(k1' c) } for rows s = 4 g + 2 rp and s + 1,
+// k1 = s mod R1, with tid = 64 w + 16 g + i, c = 64 w + 4 i + j, W = exp(-2 pi i / n), R1 = n / 256.
 inline unsigned short mfma_host_half(float f) {  // round to nearest even; |f| <= 1, no subnormal results here
   unsigned u;
   memcpy(&u, &f, 4);
@@ -61,15 +69,16 @@ inline unsigned short mfma_host_half(float f) {  // round to nearest even; |f| <
   return (unsigned short)(sign | ((rounded - 0x38000000u) >> 13));
 }
 
-inline void mfma4096_lane_twiddles(float2* dst) {
+inline void mfma_lane_tables(float2* dst, int n) {
+  const int r1 = n / 256;
   for (int j = 0; j < 4; ++j)
     for (int rp = 0; rp < 2; ++rp)
       for (int tid = 0; tid < 256; ++tid) {
         const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
         const int c = 64 * w + 4 * i + j;
         for (int h = 0; h < 2; ++h) {
-          const int k1 = 4 * g + 2 * rp + h;
-          const double a = -2.0 * M_PI * (double)((k1 * c) & 4095) / 4096.0;
+          const int k1 = (4 * g + 2 * rp + h) % r1;
+          const double a = -2.0 * M_PI * (double)((k1 * c) % n) / (double)n;
           dst[(((j * 2 + rp) * 256) + tid) * 2 + h] = make_float2((float)cos(a), (float)sin(a));
         }
       }
@@ -134,7 +143,33 @@ inline void mfma4096_lane_twiddles(float2* dst) {
       memcpy(bbase + 16 * (d * 256 + 2 * 64 + l), lo[0], 16);
       memcpy(bbase + 16 * (d * 256 + 3 * 64 + l), lo[1], 16);
     }
+  // Pass-1 matrix I (x) DFT_r1 per lane, 16-byte entry [st*256 + d*128 + q*64 + l], st = 0 fp16, 1 bf16;
+  // q = 0 real-output rows, q = 1 imaginary-output rows; row s = i, K = points rho = 4g .. 4g+3:
+  // [s / r1 == rho / r1] exp(-+2 pi i (s mod r1)(rho mod r1) / r1).
+  unsigned char* pbase = bbase + 8 * Mfma4096::BF16_FRAG_TABLE;
+  for (int st = 0; st < 2; ++st)
+    for (int d = 0; d < 2; ++d)
+      for (int l = 0; l < 64; ++l) {
+        const int g = l >> 4, i = l & 15;
+        unsigned short m[2][8];
+        for (int jj = 0; jj < 4; ++jj) {
+          const int rho = 4 * g + jj;
+          float c = 0.f, sn = 0.f;
+          if (i / r1 == rho / r1) {
+            const double a = 2.0 * M_PI * (double)(((i % r1) * (rho % r1)) % r1) / (double)r1;
+            c = (float)cos(a);
+            sn = (float)(d == 0 ? sin(a) : -sin(a));
+          }
+          const float v[2][2] = {{c, sn}, {-sn, c}};
+          for (int q = 0; q < 2; ++q)
+            for (int part = 0; part < 2; ++part)
+              m[q][2 * jj + part] = st == 0 ? mfma_host_half(v[q][part]) : bf16_rne(v[q][part]);
+        }
+        memcpy(pbase + 16 * (st * 256 + d * 128 + 0 * 64 + l), m[0], 16);
+        memcpy(pbase + 16 * (st * 256 + d * 128 + 1 * 64 + l), m[1], 16);
+      }
 }
+inline void mfma4096_lane_twiddles(float2* dst) { mfma_lane_tables(dst, Mfma4096::N); }
 
 __device__ __forceinline__ unsigned pack_f16(float re, float im) {
   const __half2 h = __float22half2_rn(make_float2(re, im));
@@ -152,8 +187,15 @@ typedef __bf16 mfma_bf8 __attribute__((ext_vector_type(8)));
 //         keep the fp32 exponent range, so there is no overflow condition beyond the result's own.
 struct MfmaF16 {
   u32x4_t re, im;
-  __device__ __forceinline__ void init(const float2* tw, bool fwd, int lane) {
-    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (fwd ? 0 : 256) + lane;
+  // tabs: the lane-ordered tables behind the n natural-order twiddles
+  __device__ __forceinline__ void init(const float2* tabs, bool fwd, int lane) {
+    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER) + (fwd ? 0 : 256) + lane;
+    re = t[0];
+    im = t[64];
+  }
+  __device__ __forceinline__ void init_pass1(const float2* tabs, bool fwd, int lane) {
+    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER + Mfma4096::FRAG_TABLE +
+                                                        Mfma4096::BF16_FRAG_TABLE) + (fwd ? 0 : 128) + lane;
     re = t[0];
     im = t[64];
   }
@@ -169,13 +211,22 @@ struct MfmaF16 {
 template <bool SPLIT>
 struct MfmaBF16T {
   u32x4_t re_hi, im_hi, re_lo, im_lo;
-  __device__ __forceinline__ void init(const float2* tw, bool fwd, int lane) {
-    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER + Mfma4096::FRAG_TABLE) +
+  __device__ __forceinline__ void init(const float2* tabs, bool fwd, int lane) {
+    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER + Mfma4096::FRAG_TABLE) +
                        (fwd ? 0 : 256) + lane;
     re_hi = t[0];
     im_hi = t[64];
     re_lo = t[128];
     im_lo = t[192];
+  }
+  // the pass-1 matrices of N < 4096 are stored unsplit (entries 0, +-1 and +-sqrt(1/2) only)
+  __device__ __forceinline__ void init_pass1(const float2* tabs, bool fwd, int lane) {
+    static_assert(!SPLIT, "the pass-1 matrix table holds no remainders");
+    const u32x4_t* t = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER + Mfma4096::FRAG_TABLE +
+                                                        Mfma4096::BF16_FRAG_TABLE) + 256 + (fwd ? 0 : 128) + lane;
+    re_hi = t[0];
+    im_hi = t[64];
+    re_lo = im_lo = u32x4_t{0u, 0u, 0u, 0u};
   }
   __device__ __forceinline__ void dft16(u32x4_t b, mfma_f4& cr, mfma_f4& ci) const {
     const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -193,40 +244,66 @@ struct MfmaBF16T {
 using MfmaBF16 = MfmaBF16T<true>;
 using MfmaBF16Single = MfmaBF16T<false>;
 
+// Where point p of the natural-order output image lives (R1 < 16): an XOR of the bank bits with
+// higher index bits, chosen per R1 so that the pass-3 writers (lanes = 16 sub-transforms x 4 row
+// groups) spread over the banks; granules of four points stay whole for the 16-byte readers.
+template <int R1>
+__device__ __forceinline__ int mfma_out_slot(int p) {
+  if (R1 == 1) return p ^ (((p >> 8) & 15) << 2);
+  if (R1 == 2) return p ^ (((p >> 9) & 7) << 2);
+  if (R1 == 4) return p ^ ((((p >> 10) & 3) << 2) | (((p >> 8) & 1) << 4));
+  if (R1 == 8) return p ^ ((((p >> 11) & 1) << 3) | (((p >> 9) & 1) << 4));
+  return p + 4 * (p >> 8);  // R1 = 16: four dwords of padding per 256
+}
+
 // DOUBLE: two LDS images (33 KiB, three barriers) instead of one (16.6 KiB, five barriers).
-// PERSIST: a resident grid; a workgroup walks transforms blockIdx.x, blockIdx.x + gridDim.x, ... and
-// requests the rows of its next transform as soon as the current rows are packed into fragments, so
+// PERSIST: a resident grid; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and
+// requests the rows of its next tile as soon as the current rows are packed into fragments, so
 // that its HBM requests stay in flight under the three passes (16 more live VGPRs).
-template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false>
+// R1 = N / 256; a tile is 4096 points = 16 / R1 transforms, `batch` counts transforms.
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16>
 __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* __restrict__ in,
                                                                      u32x4_t* __restrict__ out,
                                                                      const float2* __restrict__ tw, long long batch) {
+  static_assert(R1 == 1 || R1 == 2 || R1 == 4 || R1 == 8 || R1 == 16, "N = 256 R1");
   __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + (DOUBLE ? Mfma4096::IMG : 0)];
   unsigned* const img_a = lds;                                      // pass-2 input, later the output image
   unsigned* const img_b = DOUBLE ? lds + Mfma4096::OUT_IMG : lds;   // pass-3 input
 
   const int tid = threadIdx.x;
   const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+  const long long rows_total = batch * R1;          // rows of 256 points
+  const long long tiles = (rows_total + 15) >> 4;
   long long tr = blockIdx.x;
-  if (tr >= batch) return;
+  if (tr >= tiles) return;
+  const float2* const tabs = tw + 256 * R1;
 
-  // ---- rows first: lane (g, i) of wave w loads rows n1 = 4G + g, columns 64w + 4i .. 4i+3
+  // ---- rows first: lane (g, i) of wave w loads rows 4G + g, columns 64w + 4i .. 4i+3
   u32x4_t rows[4];
   auto request_rows = [&](long long t) {
     const u32x4_t* src = in + t * 1024 + 16 * w + i;
 #pragma unroll
-    for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
+    for (int G = 0; G < 4; ++G) {
+      if (R1 == 16 || 16 * t + 4 * G + g < rows_total)
+        rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
+      else
+        rows[G] = u32x4_t{0u, 0u, 0u, 0u};
+    }
   };
   request_rows(tr);
 
   // ---- pass-1 twiddles in lane order, the DFT-16 matrix fragments, the pass-2 twiddles
-  const float4* tw1 = reinterpret_cast<const float4*>(tw + Mfma4096::N) + tid;
-  float4 t1[8];
+  const float4* tw1 = reinterpret_cast<const float4*>(tabs) + tid;
+  float4 t1[R1 == 1 ? 1 : 8];
+  if constexpr (R1 > 1) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) t1[e] = tw1[e * 256];
-  const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
+    for (int e = 0; e < 8; ++e) t1[e] = tw1[e * 256];
+  }
+  const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER) + (tid & 63);
   T16 mat;
-  mat.init(tw, FWD, tid & 63);
+  mat.init(tabs, FWD, tid & 63);
+  T16 mat1 = mat;  // pass 1: DFT_16 when R1 = 16, else I (x) DFT_R1
+  if constexpr (R1 > 1 && R1 < 16) mat1.init_pass1(tabs, FWD, tid & 63);
   c32 t2[4];
   {
     const u32x4_t p = ftab[128], q = ftab[192];
@@ -258,27 +335,31 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     packed[j] = u32x4_t{a0, a1, a2, a3};  // rows 4g .. 4g+3 of column 64w + 4i + j
   }
   const long long next = tr + gridDim.x;
-  if (PERSIST && next < batch) request_rows(next);
+  if (PERSIST && next < tiles) request_rows(next);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     mfma_f4 cr, ci;
-    mat.dft16(packed[j], cr, ci);
-    // lane holds Y1[k1 = 4g + r][n2 = 4w + (i >> 2)][n3 = 4 (i & 3) + j]; image 2 row = (k1, n3), point n2
+    if constexpr (R1 > 1) mat1.dft16(packed[j], cr, ci);
+    // lane holds Y1[s = 4g + r][n2 = 4w + (i >> 2)][n3 = 4 (i & 3) + j]; image 2 row = (s, n3), point n2
     const int n2 = 4 * w + (i >> 2);
     const int rot = (2 * (i & 3) + (j >> 1) + g) & 3;
     const int pos = (n2 + 4 * rot) & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float4 tt = t1[j * 2 + (r >> 1)];
-      const c32 t = (r & 1) ? make_float2(tt.z, tt.w) : make_float2(tt.x, tt.y);
-      const c32 y = twiddle(cr[r], ci[r], t);
       const int row = (4 * g + r) * 16 + 4 * (i & 3) + j;
-      img_a[row * 16 + pos] = T16::pack(y.x, y.y);
+      if constexpr (R1 > 1) {
+        const float4 tt = t1[j * 2 + (r >> 1)];
+        const c32 t = (r & 1) ? make_float2(tt.z, tt.w) : make_float2(tt.x, tt.y);
+        const c32 y = twiddle(cr[r], ci[r], t);
+        img_a[row * 16 + pos] = T16::pack(y.x, y.y);
+      } else {
+        img_a[row * 16 + pos] = packed[j][r];
+      }
     }
   }
   __syncthreads();
 
-  // ---- pass 2: wave w owns k1 = 4w + t; column n3 = i, points n2 = 4g .. 4g+3
+  // ---- pass 2: wave w owns s = 4w + t; column n3 = i, points n2 = 4g .. 4g+3
   u32x4_t frag[4];
   {
     const int rot = ((i >> 1) + w) & 3;
@@ -292,7 +373,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   for (int t = 0; t < 4; ++t) {
     mfma_f4 cr, ci;
     mat.dft16(frag[t], cr, ci);
-    // lane holds Y2[k1 = 4w + t][k2 = 4g + r][n3 = i]; image 3 row = (k2, k1), point n3
+    // lane holds Y2[s = 4w + t][k2 = 4g + r][n3 = i]; image 3 row = (k2, s), point n3
     const int rot = (t + 2 * w + (t >> 1)) & 3;
     const int pos = (i + 4 * rot) & 15;
 #pragma unroll
@@ -304,7 +385,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   }
   __syncthreads();
 
-  // ---- pass 3: wave w owns k2 = 4w + t; column k1 = i, points n3 = 4g .. 4g+3
+  // ---- pass 3: wave w owns k2 = 4w + t; column s = i, points n3 = 4g .. 4g+3
   {
     const int rot = (i + (i >> 1)) & 3;
     const int gran = (g + rot) & 3;
@@ -313,16 +394,25 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
       frag[t] = *reinterpret_cast<const u32x4_t*>(&img_b[((4 * w + t) * 16 + i) * 16 + 4 * gran]);
   }
   if (!DOUBLE) __syncthreads();
+  // lane holds X of sub-transform s = i at k2 = 4w + t, k3 = 4g + r: point
+  // p = (i / R1) N + (i mod R1) + R1 (k2 + 16 k3) of the tile
+  const int p0 = (i / R1) * (256 * R1) + (i % R1) + R1 * (4 * w) + 16 * R1 * (4 * g);
+  unsigned last[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     mfma_f4 cr, ci;
     mat.dft16(frag[t], cr, ci);
-    // lane holds X[k = i + 16 (4w + t) + 256 (4g + r)]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int k3 = 4 * g + r;
-      img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = T16::pack(cr[r], ci[r]);
+      const unsigned v = T16::pack(cr[r], ci[r]);
+      if constexpr (R1 == 1) last[r][t] = v;  // t = 0..3 are four adjacent points: one 16-byte write per r below
+      else img_a[mfma_out_slot<R1>(p0 + R1 * t + 16 * R1 * r)] = v;
     }
+  }
+  if constexpr (R1 == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<u32x4_t*>(&img_a[mfma_out_slot<R1>(p0 + 16 * r)]) = u32x4_t{last[r][0], last[r][1], last[r][2], last[r][3]};
   }
   __syncthreads();
 
@@ -330,11 +420,11 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   u32x4_t* dst = out + tr * 1024 + tid;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
-    __builtin_nontemporal_store(v, dst + 256 * q);
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[mfma_out_slot<R1>(4 * (tid + 256 * q))]);
+    if (R1 == 16 || 16 * tr + 4 * q + w < rows_total) __builtin_nontemporal_store(v, dst + 256 * q);
   }
-  if (!PERSIST || next >= batch) break;
-  __syncthreads();  // the output image is read before the next transform's pass 1 overwrites it
+  if (!PERSIST || next >= tiles) break;
+  __syncthreads();  // the output image is read before the next tile's pass 1 overwrites it
   tr = next;
   }
 }

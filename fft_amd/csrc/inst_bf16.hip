@@ -7,10 +7,18 @@ bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
   switch (n) {
     case 64: return entry_for<Plan64, StoreBF16, false, Plan64Alt>(forward, mode, out);
     case 128: return entry_for<Plan128, StoreBF16, false, Plan128Alt>(forward, mode, out);
-    case 256: return entry_for<Plan256, StoreBF16, false, Plan256Alt>(forward, mode, out);
-    case 512: return entry_for<Plan512, StoreBF16, false, Plan512Alt>(forward, mode, out);
-    case 1024: return entry_for<Plan1024Alt, StoreBF16, false, Plan1024>(forward, mode, out);
-    case 2048: return entry_for<Plan2048, StoreBF16, false, Plan2048Alt>(forward, mode, out);
+    case 256:
+      if (mfma_entry_for<MfmaBF16Single, 1>(forward, mode, out)) return true;
+      return entry_for<Plan256, StoreBF16, false, Plan256Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 512:
+      if (mfma_entry_for<MfmaBF16Single, 2>(forward, mode, out)) return true;
+      return entry_for<Plan512, StoreBF16, false, Plan512Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 1024:
+      if (mfma_entry_for<MfmaBF16Single, 4>(forward, mode, out)) return true;
+      return entry_for<Plan1024Alt, StoreBF16, false, Plan1024>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 2048:
+      if (mfma_entry_for<MfmaBF16Single, 8>(forward, mode, out)) return true;
+      return entry_for<Plan2048, StoreBF16, false, Plan2048Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
     case 4096:
       // Default: three passes on the matrix cores with bf16 operands, resident prefetching grid
       // (rel-L2 3.5e-3 against the 1e-2 gate; 68 % of HBM). Mode 8: the same with the DFT matrix split

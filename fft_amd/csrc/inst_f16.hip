@@ -7,10 +7,18 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
   switch (n) {
     case 64: return entry_for<Plan64, StoreF16, false, Plan64Alt>(forward, mode, out);
     case 128: return entry_for<Plan128, StoreF16, false, Plan128Alt>(forward, mode, out);
-    case 256: return entry_for<Plan256, StoreF16, false, Plan256Alt>(forward, mode, out);
-    case 512: return entry_for<Plan512, StoreF16, false, Plan512Alt>(forward, mode, out);
-    case 1024: return entry_for<Plan1024Alt, StoreF16, false, Plan1024>(forward, mode, out);
-    case 2048: return entry_for<Plan2048, StoreF16, false, Plan2048Alt>(forward, mode, out);
+    case 256:
+      if (mfma_entry_for<MfmaF16, 1>(forward, mode, out)) return true;
+      return entry_for<Plan256, StoreF16, false, Plan256Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 512:
+      if (mfma_entry_for<MfmaF16, 2>(forward, mode, out)) return true;
+      return entry_for<Plan512, StoreF16, false, Plan512Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 1024:
+      if (mfma_entry_for<MfmaF16, 4>(forward, mode, out)) return true;
+      return entry_for<Plan1024Alt, StoreF16, false, Plan1024>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 2048:
+      if (mfma_entry_for<MfmaF16, 8>(forward, mode, out)) return true;
+      return entry_for<Plan2048, StoreF16, false, Plan2048Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
     case 4096:
       // Default: all three passes on the matrix cores, resident grid with row prefetch, two LDS images
       // (fft_mfma_kernel.hpp). Mode 3: the VALU kernel; 4: VALU with the middle pass on the matrix

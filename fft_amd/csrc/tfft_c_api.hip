@@ -230,16 +230,17 @@ int tfft_initialize(int dtype, int n) {
   if (g_plans.count(key)) return TFFT_OK;
 
   DevicePlan p;
-  // n = 4096: the table is followed by the lane-ordered tables of the matrix-core kernel
-  const size_t entries = (size_t)n + (n == tfft::Mfma4096::N ? tfft::Mfma4096::TABLES + tfft::ConvMfma4096::TABLE : 0);
+  // n = 256 ... 4096: the table is followed by the lane-ordered tables of the matrix-core kernels
+  const bool mfma_tables = n >= 256 && n <= tfft::Mfma4096::N;
+  const size_t entries = (size_t)n + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (n == tfft::Mfma4096::N ? tfft::ConvMfma4096::TABLE : 0);
   std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
     // exact reduction of the angle: j/n is a dyadic rational, evaluated in fp64 and rounded once
     const double a = -2.0 * M_PI * (double)j / (double)n;
     h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
   }
+  if (mfma_tables) tfft::mfma_lane_tables(h.data() + n, n);
   if (n == tfft::Mfma4096::N) {
-    tfft::mfma4096_lane_twiddles(h.data() + n);
     tfft::conv_mfma4096_tables(h.data() + tfft::ConvMfma4096::OFFSET);
   }
   TFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p.tw), sizeof(float2) * entries));

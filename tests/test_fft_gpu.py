@@ -249,6 +249,45 @@ def test_bf16_4096_plans_vs_oracle(oracle_mod, mode, forward):
     assert worst <= TOL["bf16"], worst
 
 
+@pytest.mark.parametrize("kind", ("fp16", "bf16"))
+@pytest.mark.parametrize("n", (256, 512, 1024, 2048))
+@pytest.mark.parametrize("mode", (0, 3, 4, 6))
+def test_half_storage_matrix_core_lengths(oracle_mod, n, kind, mode):
+    """16-bit storage, N = 256 ... 2048: mode 0 (default) and 6 run on the matrix cores (16 / (N / 256)
+    transforms per workgroup, resident grid or one workgroup per tile), modes 3 and 4 are the fp32 VALU
+    kernels. Batches that leave a partial tile and batches of several tiles per workgroup, per-transform
+    errors (a misplaced row would hide in the aggregate), both directions, out of place and in place."""
+    per_tile = 4096 // n
+    for batch in (1, per_tile + 1, 3 * 768 * per_tile + per_tile // 2 + 1):
+        scale = 1.0 / np.sqrt(n) if kind == "fp16" else 1.0
+        x = (synth.uniform_complex(batch, n, seed=n + batch) * scale).astype(np.complex64)
+        for forward in (True, False):
+            for inplace in (False, True):
+                try:
+                    fft_amd.set_option("mode", mode)
+                    got, stored = run(x, kind, forward, inplace=inplace)
+                finally:
+                    fft_amd.set_option("mode", 0)
+                ref = oracle_mod.fft(stored, forward)
+                err = oracle_mod.rel_l2(got, ref)
+                assert err <= TOL[kind], f"{kind} n={n} mode={mode} batch={batch} forward={forward} rel_l2={err:.3e}"
+                step = max(1, batch // 97)
+                worst = max(oracle_mod.rel_l2(got[b], ref[b]) for b in list(range(0, batch, step)) + [batch - 1])
+                assert worst <= TOL[kind], (n, mode, batch, forward, worst)
+
+
+def test_matrix_core_tail_does_not_write_past_the_batch():
+    n, batch, extra = 512, 13, 11  # 8 transforms per tile: the last tile is partial
+    x = synth.uniform_complex(batch + extra, n, seed=5) / np.sqrt(n)
+    d = to_device(x.astype(np.complex64), "fp16")
+    out = torch.full_like(d, 123.0)
+    fft_amd.ThunderFFTInitialize("fp16", n)
+    fft_amd.ThunderFFT_global(d, out, batch, n, True)
+    torch.cuda.synchronize()
+    assert torch.all(out[batch:] == 123.0)
+    assert not torch.any(out[:batch] == 123.0)
+
+
 def test_fp16_4096_in_place_and_small_batches(oracle_mod):
     # the default fp16 kernel is a resident grid: in place, and batches smaller than the grid
     n = 4096
