@@ -53,7 +53,8 @@ struct Mfma4096 {
   static constexpr int FRAG_TABLE = 1024;     // then, per direction: matrix fragments and pass-2 twiddles per lane
   static constexpr int BF16_FRAG_TABLE = 1024;  // then, per direction: the matrix as bf16 high and low parts per lane
   static constexpr int P1_TABLE = 512;  // then, per storage type and direction: the pass-1 matrix of N < 4096 per lane
-  static constexpr int TABLES = TW_LANE_ORDER + FRAG_TABLE + BF16_FRAG_TABLE + 2 * P1_TABLE;
+  static constexpr int INCR_TABLE = 1024 + 16;  // then start and step values of the incrementally built pass-1 twiddles
+  static constexpr int TABLES = TW_LANE_ORDER + FRAG_TABLE + BF16_FRAG_TABLE + 2 * P1_TABLE + INCR_TABLE;
 };
 
 // Host side: the pass-1 twiddles in the order the kernel's lanes consume them. Entry
@@ -168,8 +169,22 @@ inline void mfma_lane_tables(float2* dst, int n) {
         memcpy(pbase + 16 * (st * 256 + d * 128 + 0 * 64 + l), m[0], 16);
         memcpy(pbase + 16 * (st * 256 + d * 128 + 1 * 64 + l), m[1], 16);
       }
+  // Incremental pass-1 twiddles: float4 start [h][tid] = { W^(k1 c0), W^(k1' c0) } for rows s = 4g + 2h and s + 1,
+  // c0 = 64w + 4i, then float4 step [h][g] = { W^k1, W^k1' }; k1 = s mod r1.
+  float2* inc = reinterpret_cast<float2*>(pbase + 16 * 512);
+  auto wn = [n](long long e) {
+    const double a = -2.0 * M_PI * (double)(e % n) / (double)n;
+    return make_float2((float)cos(a), (float)sin(a));
+  };
+  for (int h = 0; h < 2; ++h) {
+    for (int tid = 0; tid < 256; ++tid) {
+      const int wv = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+      for (int u = 0; u < 2; ++u) inc[2 * (h * 256 + tid) + u] = wn((long long)((4 * g + 2 * h + u) % r1) * (64 * wv + 4 * i));
+    }
+    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < 2; ++u) inc[2 * (512 + h * 4 + g) + u] = wn((4 * g + 2 * h + u) % r1);
+  }
 }
-inline void mfma4096_lane_twiddles(float2* dst) { mfma_lane_tables(dst, Mfma4096::N); }
 
 __device__ __forceinline__ unsigned pack_f16(float re, float im) {
   const __half2 h = __float22half2_rn(make_float2(re, im));
@@ -244,16 +259,20 @@ struct MfmaBF16T {
 using MfmaBF16 = MfmaBF16T<true>;
 using MfmaBF16Single = MfmaBF16T<false>;
 
-// Where point p of the natural-order output image lives (R1 < 16): an XOR of the bank bits with
-// higher index bits, chosen per R1 so that the pass-3 writers (lanes = 16 sub-transforms x 4 row
-// groups) spread over the banks; granules of four points stay whole for the 16-byte readers.
+// Where point p of the natural-order output image lives: padding that grows with the higher index
+// bits, chosen per R1 so that the pass-3 writers (lanes = 16 sub-transforms x 4 row groups) spread
+// over the banks while the offsets between a lane's 16 values stay compile-time constants; always a
+// multiple of four dwords, so the 16-byte readers find their granules whole.
 template <int R1>
 __device__ __forceinline__ int mfma_out_slot(int p) {
-  if (R1 == 1) return p ^ (((p >> 8) & 15) << 2);
-  if (R1 == 2) return p ^ (((p >> 9) & 7) << 2);
-  if (R1 == 4) return p ^ ((((p >> 10) & 3) << 2) | (((p >> 8) & 1) << 4));
-  if (R1 == 8) return p ^ ((((p >> 11) & 1) << 3) | (((p >> 9) & 1) << 4));
-  return p + 4 * (p >> 8);  // R1 = 16: four dwords of padding per 256
+  if (R1 == 8) return p + 16 * (p >> 9) + 8 * (p >> 11);
+  if (R1 == 4) return p + 16 * (p >> 8) + 4 * (p >> 10);
+  if (R1 == 2) return p + 4 * (p >> 9);
+  return p + 4 * (p >> 8);  // R1 = 1, 16
+}
+template <int R1>
+constexpr int mfma_out_words() {
+  return 4096 + (R1 == 8 ? 128 : R1 == 4 ? 256 : 64);
 }
 
 // DOUBLE: two LDS images (33 KiB, three barriers) instead of one (16.6 KiB, five barriers).
@@ -261,14 +280,19 @@ __device__ __forceinline__ int mfma_out_slot(int p) {
 // requests the rows of its next tile as soon as the current rows are packed into fragments, so
 // that its HBM requests stay in flight under the three passes (16 more live VGPRs).
 // R1 = N / 256; a tile is 4096 points = 16 / R1 transforms, `batch` counts transforms.
-template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16>
+// INCR: the pass-1 twiddles W^(k1 c) of the four columns c0 .. c0 + 3 of a lane are built from W^(k1 c0)
+// and the step W^k1 (32 + 32 bytes of tables per lane instead of 128; 12 more complex multiplications per tile).
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false>
 __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* __restrict__ in,
                                                                      u32x4_t* __restrict__ out,
                                                                      const float2* __restrict__ tw, long long batch) {
   static_assert(R1 == 1 || R1 == 2 || R1 == 4 || R1 == 8 || R1 == 16, "N = 256 R1");
-  __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + (DOUBLE ? Mfma4096::IMG : 0)];
-  unsigned* const img_a = lds;                                      // pass-2 input, later the output image
-  unsigned* const img_b = DOUBLE ? lds + Mfma4096::OUT_IMG : lds;   // pass-3 input
+  static_assert(!INCR || R1 > 1, "N = 256 has no first pass");
+  constexpr int OUT_WORDS = mfma_out_words<R1>();
+  static_assert(mfma_out_words<16>() == Mfma4096::OUT_IMG, "the convolution kernels share the N = 4096 image");
+  __shared__ __attribute__((aligned(16))) unsigned lds[OUT_WORDS + (DOUBLE ? Mfma4096::IMG : 0)];
+  unsigned* const img_a = lds;                              // pass-2 input, later the output image
+  unsigned* const img_b = DOUBLE ? lds + OUT_WORDS : lds;   // pass-3 input
 
   const int tid = threadIdx.x;
   const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
@@ -279,23 +303,31 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   const float2* const tabs = tw + 256 * R1;
 
   // ---- rows first: lane (g, i) of wave w loads rows 4G + g, columns 64w + 4i .. 4i+3
+  // Rows past the batch (last tile when N < 4096) re-read the tile's last valid row: their results are never
+  // stored, and the matrix of pass 1 has zeros between different transforms.
   u32x4_t rows[4];
+  auto last_row = [&](long long t) { return R1 == 16 ? 15 : (int)min(15LL, rows_total - 16 * t - 1); };
   auto request_rows = [&](long long t) {
     const u32x4_t* src = in + t * 1024 + 16 * w + i;
+    const int last = last_row(t);
 #pragma unroll
-    for (int G = 0; G < 4; ++G) {
-      if (R1 == 16 || 16 * t + 4 * G + g < rows_total)
-        rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
-      else
-        rows[G] = u32x4_t{0u, 0u, 0u, 0u};
-    }
+    for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + min(4 * G + g, last) * 64);
   };
   request_rows(tr);
 
   // ---- pass-1 twiddles in lane order, the DFT-16 matrix fragments, the pass-2 twiddles
   const float4* tw1 = reinterpret_cast<const float4*>(tabs) + tid;
-  float4 t1[R1 == 1 ? 1 : 8];
-  if constexpr (R1 > 1) {
+  float4 t1[R1 == 1 || INCR ? 1 : 8];
+  c32 start[4], step[4];
+  if constexpr (INCR) {
+    // start [h][tid] = { W^(k1 c0), W^(k1' c0) } for rows s = 4g + 2h and s + 1, c0 = 64w + 4i; step [h][g] = { W^k1, W^k1' }
+    const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE);
+    const float4 s0 = ctab[tid], s1 = ctab[256 + tid], q0 = ctab[512 + g], q1 = ctab[516 + g];
+    start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
+    start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);
+    step[0] = make_float2(q0.x, q0.y); step[1] = make_float2(q0.z, q0.w);
+    step[2] = make_float2(q1.x, q1.y); step[3] = make_float2(q1.z, q1.w);
+  } else if constexpr (R1 > 1) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) t1[e] = tw1[e * 256];
   }
@@ -336,6 +368,11 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   }
   const long long next = tr + gridDim.x;
   if (PERSIST && next < tiles) request_rows(next);
+  c32 run[4];
+  if constexpr (INCR) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) run[r] = start[r];
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     mfma_f4 cr, ci;
@@ -347,7 +384,11 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = (4 * g + r) * 16 + 4 * (i & 3) + j;
-      if constexpr (R1 > 1) {
+      if constexpr (INCR) {
+        const c32 y = twiddle(cr[r], ci[r], run[r]);
+        img_a[row * 16 + pos] = T16::pack(y.x, y.y);
+        if (j < 3) run[r] = cmul(run[r], step[r]);
+      } else if constexpr (R1 > 1) {
         const float4 tt = t1[j * 2 + (r >> 1)];
         const c32 t = (r & 1) ? make_float2(tt.z, tt.w) : make_float2(tt.x, tt.y);
         const c32 y = twiddle(cr[r], ci[r], t);
@@ -396,7 +437,9 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   if (!DOUBLE) __syncthreads();
   // lane holds X of sub-transform s = i at k2 = 4w + t, k3 = 4g + r: point
   // p = (i / R1) N + (i mod R1) + R1 (k2 + 16 k3) of the tile
-  const int p0 = (i / R1) * (256 * R1) + (i % R1) + R1 * (4 * w) + 16 * R1 * (4 * g);
+  // (the padding of mfma_out_slot is the same for a lane's 16 values, or grows by 4 per r when R1 = 16)
+  const int slot0 = mfma_out_slot<R1>((i / R1) * (256 * R1) + (i % R1) + R1 * (4 * w) + 16 * R1 * (4 * g));
+  constexpr int R_STEP = 16 * R1 + (R1 == 16 ? 4 : 0);
   unsigned last[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -406,22 +449,23 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     for (int r = 0; r < 4; ++r) {
       const unsigned v = T16::pack(cr[r], ci[r]);
       if constexpr (R1 == 1) last[r][t] = v;  // t = 0..3 are four adjacent points: one 16-byte write per r below
-      else img_a[mfma_out_slot<R1>(p0 + R1 * t + 16 * R1 * r)] = v;
+      else img_a[slot0 + R1 * t + R_STEP * r] = v;
     }
   }
   if constexpr (R1 == 1) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<u32x4_t*>(&img_a[mfma_out_slot<R1>(p0 + 16 * r)]) = u32x4_t{last[r][0], last[r][1], last[r][2], last[r][3]};
+      *reinterpret_cast<u32x4_t*>(&img_a[slot0 + R_STEP * r]) = u32x4_t{last[r][0], last[r][1], last[r][2], last[r][3]};
   }
   __syncthreads();
 
   // ---- natural order out, 16 bytes per lane
+  const int last_cur = last_row(tr);
   u32x4_t* dst = out + tr * 1024 + tid;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[mfma_out_slot<R1>(4 * (tid + 256 * q))]);
-    if (R1 == 16 || 16 * tr + 4 * q + w < rows_total) __builtin_nontemporal_store(v, dst + 256 * q);
+    if (R1 == 16 || 4 * q + w <= last_cur) __builtin_nontemporal_store(v, dst + 256 * q);
   }
   if (!PERSIST || next >= tiles) break;
   __syncthreads();  // the output image is read before the next tile's pass 1 overwrites it

@@ -20,11 +20,13 @@ bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
       if (mfma_entry_for<MfmaBF16Single, 8>(forward, mode, out)) return true;
       return entry_for<Plan2048, StoreBF16, false, Plan2048Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
     case 4096:
-      // Default: three passes on the matrix cores with bf16 operands, resident prefetching grid
-      // (rel-L2 3.5e-3 against the 1e-2 gate; 68 % of HBM). Mode 8: the same with the DFT matrix split
-      // into bf16 high and low parts (2.9e-3, 62 %); 6: split matrix, one workgroup per transform;
-      // 3: the fp32 VALU kernel (1.7e-3, 56 %).
-      if (mode == 0) { *out = forward ? make_mfma_entry<MfmaBF16Single, true, true, 4, true>() : make_mfma_entry<MfmaBF16Single, false, true, 4, true>(); return true; }
+      // Default: three passes on the matrix cores with bf16 operands, one workgroup per transform, pass-1
+      // twiddles built incrementally (rel-L2 3.5e-3 against the 1e-2 gate). Mode 11: the kernel with the
+      // lane-ordered twiddle table as a resident prefetching grid; 8: that with the DFT matrix split into bf16
+      // high and low parts (2.9e-3, 6 points of bandwidth slower); 6: split matrix, one workgroup per
+      // transform; 3: the fp32 VALU kernel (1.7e-3).
+      if (mode == 0 || mode == 10) { *out = forward ? make_mfma_entry<MfmaBF16Single, true, true, 4, false, 16, true>() : make_mfma_entry<MfmaBF16Single, false, true, 4, false, 16, true>(); return true; }
+      if (mode == 11) { *out = forward ? make_mfma_entry<MfmaBF16Single, true, true, 4, true>() : make_mfma_entry<MfmaBF16Single, false, true, 4, true>(); return true; }
       if (mode == 8) { *out = forward ? make_mfma_entry<MfmaBF16, true, true, 4, true>() : make_mfma_entry<MfmaBF16, false, true, 4, true>(); return true; }
       if (mode == 6) { *out = forward ? make_mfma_entry<MfmaBF16, true, true, 4>() : make_mfma_entry<MfmaBF16, false, true, 4>(); return true; }
       if (mode == 3) mode = 0;

@@ -20,11 +20,14 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
       if (mfma_entry_for<MfmaF16, 8>(forward, mode, out)) return true;
       return entry_for<Plan2048, StoreF16, false, Plan2048Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
     case 4096:
-      // Default: all three passes on the matrix cores, resident grid with row prefetch, two LDS images
-      // (fft_mfma_kernel.hpp). Mode 3: the VALU kernel; 4: VALU with the middle pass on the matrix
-      // cores; 5 / 6: matrix cores, one workgroup per transform, one / two LDS images; 7: resident with
-      // one LDS image; 9: VALU kernel as a resident prefetching grid.
-      if (mode == 0) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4, true>() : make_mfma_entry<MfmaF16, false, true, 4, true>(); return true; }
+      // All three passes on the matrix cores (fft_mfma_kernel.hpp). Default: one workgroup per transform, pass-1
+      // twiddles built incrementally, two LDS images. 12: the same with one LDS image; 5 / 6: one workgroup per
+      // transform, twiddles from the lane-ordered table, one / two LDS images; 11 / 7: that kernel as a resident
+      // grid with row prefetch, two / one LDS images. Mode 3: the VALU kernel; 4: VALU with the middle pass on the
+      // matrix cores; 9: VALU kernel as a resident prefetching grid.
+      if (mode == 0 || mode == 10) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4, false, 16, true>() : make_mfma_entry<MfmaF16, false, true, 4, false, 16, true>(); return true; }
+      if (mode == 12) { *out = forward ? make_mfma_entry<MfmaF16, true, false, 8, false, 16, true>() : make_mfma_entry<MfmaF16, false, false, 8, false, 16, true>(); return true; }
+      if (mode == 11) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4, true>() : make_mfma_entry<MfmaF16, false, true, 4, true>(); return true; }
       if (mode == 5) { *out = forward ? make_mfma_entry<MfmaF16, true, false, 4>() : make_mfma_entry<MfmaF16, false, false, 4>(); return true; }
       if (mode == 6) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4>() : make_mfma_entry<MfmaF16, false, true, 4>(); return true; }
       if (mode == 7) { *out = forward ? make_mfma_entry<MfmaF16, true, false, 4, true>() : make_mfma_entry<MfmaF16, false, false, 4, true>(); return true; }

@@ -121,21 +121,21 @@ KernelEntry make_entry() {
 }
 
 // Matrix-core kernel of fft_mfma_kernel.hpp as a table entry: N = 256 R1, 16 / R1 transforms per workgroup.
-template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST, int R1>
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST, int R1, bool INCR>
 void launch_mfma4096(const void* in, void* out, const float2* tw, long long batch, long long nchunks, unsigned grid,
                      unsigned extra_lds, hipStream_t stream) {
   (void)extra_lds;
   // one-shot: one workgroup per tile of 4096 points; resident: the caller's grid (workgroups per CU x CUs)
   const unsigned blocks = PERSIST ? grid : (unsigned)nchunks;
-  fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1><<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(
+  fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR><<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(
       static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch);
 }
 
-template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16>
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false>
 KernelEntry make_mfma_entry() {
   KernelEntry e;
-  e.fn = reinterpret_cast<const void*>(&fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1>);
-  e.launch = &launch_mfma4096<T16, FWD, DOUBLE, MINW, PERSIST, R1>;
+  e.fn = reinterpret_cast<const void*>(&fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR>);
+  e.launch = &launch_mfma4096<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR>;
   e.n = 256 * R1;
   e.threads = Mfma4096::WG;
   e.tpb = 16 / R1;
@@ -143,17 +143,24 @@ KernelEntry make_mfma_entry() {
   e.radix[0] = R1 == 1 ? 16 : R1;
   e.radix[1] = 16;
   e.radix[2] = R1 == 1 ? 1 : 16;
-  e.lds_bytes = 4 * (Mfma4096::OUT_IMG + (DOUBLE ? Mfma4096::IMG : 0));
+  e.lds_bytes = 4 * (mfma_out_words<R1>() + (DOUBLE ? Mfma4096::IMG : 0));
   // three workgroups per CU measured best for the resident form (two: 66 %, three: 72-75 %, four: 67 %)
   e.resident_per_cu = PERSIST ? 3 : 0;
   return e;
 }
 
-// The matrix-core kernel of one 16-bit storage type for N = 256 R1 < 4096: mode 0 resident, mode 6 one workgroup per tile.
+// The matrix-core kernels of one 16-bit storage type for N = 256 R1 < 4096. Mode 0, the default: N = 256 (no first
+// pass, no twiddle table to fetch) one workgroup per tile with one LDS image; otherwise a resident grid with the
+// pass-1 twiddles from the lane-ordered table. 6: one workgroup per tile, table; 10: one workgroup per tile, twiddles
+// built incrementally; 12: the same with one LDS image (eight workgroups per CU); 11: resident grid.
 template <class T16, int R1>
 bool mfma_entry_for(bool forward, int mode, KernelEntry* out) {
-  if (mode == 0) { *out = forward ? make_mfma_entry<T16, true, true, 3, true, R1>() : make_mfma_entry<T16, false, true, 3, true, R1>(); return true; }
+  constexpr bool INCR = R1 > 1;
+  if (mode == 0) mode = R1 == 1 ? 12 : 11;
+  if (mode == 11) { *out = forward ? make_mfma_entry<T16, true, true, 3, true, R1>() : make_mfma_entry<T16, false, true, 3, true, R1>(); return true; }
   if (mode == 6) { *out = forward ? make_mfma_entry<T16, true, true, 4, false, R1>() : make_mfma_entry<T16, false, true, 4, false, R1>(); return true; }
+  if (mode == 10) { *out = forward ? make_mfma_entry<T16, true, true, 4, false, R1, INCR>() : make_mfma_entry<T16, false, true, 4, false, R1, INCR>(); return true; }
+  if (mode == 12) { *out = forward ? make_mfma_entry<T16, true, false, 8, false, R1, INCR>() : make_mfma_entry<T16, false, false, 8, false, R1, INCR>(); return true; }
   return false;
 }
 

@@ -199,15 +199,16 @@ def test_alternative_plans_vs_oracle(oracle_mod, n, mode):
         fft_amd.set_option("grid_blocks_per_cu", 0)
 
 
-@pytest.mark.parametrize("mode", [0, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("mode", [0, 3, 4, 5, 6, 7, 11, 12])
 @pytest.mark.parametrize("forward", (True, False))
 def test_fp16_4096_plans_vs_oracle(oracle_mod, mode, forward):
-    """fp16 storage, N = 4096. Mode 0 (default), 5, 6, 7: all three passes on the matrix cores (fp16
-    operands, fp32 accumulation, data rounded to fp16 between passes), as a resident prefetching grid
-    (0, 7) or one workgroup per transform (5, 6); mode 3: the fp32 VALU kernel; mode 4: VALU with the
-    middle pass on the matrix cores. Same gate for all, and a tighter regression bound."""
+    """fp16 storage, N = 4096. Mode 0 (default), 5, 6, 7, 11, 12: all three passes on the matrix cores (fp16
+    operands, fp32 accumulation, data rounded to fp16 between passes), one workgroup per transform (0 and 12
+    with the pass-1 twiddles built incrementally, 5 and 6 from a table) or as a resident prefetching grid
+    (7, 11); mode 3: the fp32 VALU kernel; mode 4: VALU with the middle pass on the matrix cores. Same gate
+    for all, and a tighter regression bound."""
     n = 4096
-    batch = 2500 if mode in (0, 7) else 37  # resident grids: several transforms per workgroup, uneven tail
+    batch = 2500 if mode in (7, 11) else 37  # resident grids: several transforms per workgroup, uneven tail
     x = synth.uniform_complex(batch, n, seed=mode) / np.sqrt(n)  # the reference's input scale, sample/bench/main.cu:36
     try:
         fft_amd.set_option("mode", mode)
@@ -227,14 +228,14 @@ def test_fp16_4096_plans_vs_oracle(oracle_mod, mode, forward):
     assert worst <= TOL["fp16"], worst
 
 
-@pytest.mark.parametrize("mode", [0, 3, 6, 8])
+@pytest.mark.parametrize("mode", [0, 3, 6, 8, 11])
 @pytest.mark.parametrize("forward", (True, False))
 def test_bf16_4096_plans_vs_oracle(oracle_mod, mode, forward):
-    """bf16 storage, N = 4096. Mode 0 (default): matrix cores with bf16 operands; modes 6 and 8: the DFT
-    matrix split into bf16 high and low parts; mode 3: the fp32 VALU kernel. Unscaled inputs: bf16
-    intermediates keep the fp32 range."""
+    """bf16 storage, N = 4096. Mode 0 (default, one workgroup per transform) and 11 (resident grid): matrix
+    cores with bf16 operands; modes 6 and 8: the DFT matrix split into bf16 high and low parts; mode 3: the
+    fp32 VALU kernel. Unscaled inputs: bf16 intermediates keep the fp32 range."""
     n = 4096
-    batch = 2500 if mode in (0, 8) else 37
+    batch = 2500 if mode in (11, 8) else 37
     x = synth.uniform_complex(batch, n, seed=40 + mode)
     try:
         fft_amd.set_option("mode", mode)
@@ -251,10 +252,11 @@ def test_bf16_4096_plans_vs_oracle(oracle_mod, mode, forward):
 
 @pytest.mark.parametrize("kind", ("fp16", "bf16"))
 @pytest.mark.parametrize("n", (256, 512, 1024, 2048))
-@pytest.mark.parametrize("mode", (0, 3, 4, 6))
+@pytest.mark.parametrize("mode", (0, 3, 4, 6, 10, 11, 12))
 def test_half_storage_matrix_core_lengths(oracle_mod, n, kind, mode):
-    """16-bit storage, N = 256 ... 2048: mode 0 (default) and 6 run on the matrix cores (16 / (N / 256)
-    transforms per workgroup, resident grid or one workgroup per tile), modes 3 and 4 are the fp32 VALU
+    """16-bit storage, N = 256 ... 2048: modes 0 (default), 6, 10, 11, 12 run on the matrix cores (16 / (N / 256)
+    transforms per workgroup; 11 a resident grid, the others one workgroup per tile with the pass-1 twiddles
+    from a table or built incrementally and one or two LDS images), modes 3 and 4 are the fp32 VALU
     kernels. Batches that leave a partial tile and batches of several tiles per workgroup, per-transform
     errors (a misplaced row would hide in the aggregate), both directions, out of place and in place."""
     per_tile = 4096 // n
