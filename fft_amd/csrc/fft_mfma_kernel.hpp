@@ -53,7 +53,7 @@ struct Mfma4096 {
   static constexpr int FRAG_TABLE = 1024;     // then, per direction: matrix fragments and pass-2 twiddles per lane
   static constexpr int BF16_FRAG_TABLE = 1024;  // then, per direction: the matrix as bf16 high and low parts per lane
   static constexpr int P1_TABLE = 512;  // then, per storage type and direction: the pass-1 matrix of N < 4096 per lane
-  static constexpr int INCR_TABLE = 1024 + 16;  // then start and step values of the incrementally built pass-1 twiddles
+  static constexpr int INCR_TABLE = 2 * (1024 + 16);  // then start and step values of the incrementally built pass-1 twiddles, two column maps
   static constexpr int TABLES = TW_LANE_ORDER + FRAG_TABLE + BF16_FRAG_TABLE + 2 * P1_TABLE + INCR_TABLE;
 };
 
@@ -184,6 +184,16 @@ inline void mfma_lane_tables(float2* dst, int n) {
     for (int g = 0; g < 4; ++g)
       for (int u = 0; u < 2; ++u) inc[2 * (512 + h * 4 + g) + u] = wn((4 * g + 2 * h + u) % r1);
   }
+  // The same for lanes that hold columns 64w + 16j + i, j = 0..3: start at c0 = 64w + i, step W^(16 k1).
+  float2* inc2 = inc + 1024 + 16;
+  for (int h = 0; h < 2; ++h) {
+    for (int tid = 0; tid < 256; ++tid) {
+      const int wv = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+      for (int u = 0; u < 2; ++u) inc2[2 * (h * 256 + tid) + u] = wn((long long)((4 * g + 2 * h + u) % r1) * (64 * wv + i));
+    }
+    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < 2; ++u) inc2[2 * (512 + h * 4 + g) + u] = wn(16LL * ((4 * g + 2 * h + u) % r1));
+  }
 }
 
 __device__ __forceinline__ unsigned pack_f16(float re, float im) {
@@ -221,6 +231,7 @@ struct MfmaF16 {
     ci = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_h8, im), bv, zero, 0, 0, 0);
   }
   static __device__ __forceinline__ unsigned pack(float re_, float im_) { return pack_f16(re_, im_); }
+  static __device__ __forceinline__ c32 unpack(unsigned v) { return __half22float2(*reinterpret_cast<const __half2*>(&v)); }
 };
 
 template <bool SPLIT>
@@ -255,6 +266,7 @@ struct MfmaBF16T {
     ci = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf8, im_hi), bv, ci, 0, 0, 0);
   }
   static __device__ __forceinline__ unsigned pack(float re_, float im_) { return StoreBF16::cvt(make_float2(re_, im_)); }
+  static __device__ __forceinline__ c32 unpack(unsigned v) { return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)); }
 };
 using MfmaBF16 = MfmaBF16T<true>;
 using MfmaBF16Single = MfmaBF16T<false>;
@@ -470,6 +482,200 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   if (!PERSIST || next >= tiles) break;
   __syncthreads();  // the output image is read before the next tile's pass 1 overwrites it
   tr = next;
+  }
+}
+
+// N = 4096 R0, R0 = 2 or 4, 16-bit storage: decimation in time over R0 around the 4096-point passes.
+// The R0 interleaved subsequences x[R0 n' + r0] are transformed one after the other (F_r0, the three
+// matrix-core passes above through the same two LDS images), and
+//   X[k' + 4096 k0] = sum_r0 W_R0^(r0 k0) W_N^(r0 k') F_r0[k']
+// is a radix-R0 butterfly across results that sit in the same lane and register slot, in fp32. The R0
+// points n' = c of the subsequences are 4 R0 contiguous bytes, one load of a lane: de-interleaving is
+// register naming, and a lane takes columns c = 64w + 16j + i, j = 0..3, so that the 16 lanes of a row read
+// contiguous memory. Every output block k0 is 4096 contiguous points and leaves through the
+// natural-order image like a 4096-point transform. One workgroup per transform. The final twiddles are
+// W^(r0 (i + 64w + 1024g)) (one gather per lane from the natural-order table) times the wave-uniform
+// W^(16 r0 t) and W^(256 r0 r). `tw` holds the N natural-order twiddles followed by the lane-ordered
+// tables of N = 4096.
+template <class T16, bool FWD, int R0, int MINW>
+__global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* __restrict__ in, u32x4_t* __restrict__ out,
+                                                                     const float2* __restrict__ tw, long long batch) {
+  static_assert(R0 == 2 || R0 == 4, "N = 8192 or 16384");
+  constexpr int N = 4096 * R0;
+  constexpr int OUT_WORDS = mfma_out_words<16>();
+  __shared__ __attribute__((aligned(16))) unsigned lds[2 * OUT_WORDS];
+  unsigned* const img_a = lds;              // pass-2 input; at the end the output image of even k0
+  unsigned* const img_b = lds + OUT_WORDS;  // pass-3 input; at the end the output image of odd k0
+
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+  const long long tr = blockIdx.x;
+  if (tr >= batch) return;
+  const float2* const tabs = tw + N;
+
+  // ---- all rows first: lane (g, i) of wave w, row rho = 4G + g, columns c = 64w + 16j + i: points R0 (256 rho + c) + r0
+  typedef unsigned vec_t __attribute__((ext_vector_type(R0)));
+  vec_t L[4][4];
+  {
+    const vec_t* src = reinterpret_cast<const vec_t*>(in) + tr * 4096 + 64 * w + i;
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L[G][j] = __builtin_nontemporal_load(src + 256 * (4 * G + g) + 16 * j);
+  }
+
+  // ---- constants of the 4096-point passes
+  T16 mat;
+  mat.init(tabs, FWD, tid & 63);
+  c32 start[4], step[4], t2[4];
+  {
+    const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE / 2);
+    const float4 s0 = ctab[tid], s1 = ctab[256 + tid], q0 = ctab[512 + g], q1 = ctab[516 + g];
+    start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
+    start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);
+    step[0] = make_float2(q0.x, q0.y); step[1] = make_float2(q0.z, q0.w);
+    step[2] = make_float2(q1.x, q1.y); step[3] = make_float2(q1.z, q1.w);
+    const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER) + (tid & 63);
+    const u32x4_t p = ftab[128], q = ftab[192];
+    t2[0] = make_float2(__uint_as_float(p.x), __uint_as_float(p.y));
+    t2[1] = make_float2(__uint_as_float(p.z), __uint_as_float(p.w));
+    t2[2] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+    t2[3] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
+  }
+  auto twiddle = [](float re, float im, c32 t) {
+    if (FWD) return make_float2(re * t.x - im * t.y, re * t.y + im * t.x);
+    return make_float2(re * t.x + im * t.y, im * t.x - re * t.y);
+  };
+
+  unsigned res[R0][4][4];  // [r0][t][r]: F_r0[k' = i + 16 (4w + t) + 256 (4g + r)], later X[k' + 4096 k0] at [k0]
+#pragma unroll
+  for (int r0 = 0; r0 < R0; ++r0) {
+    // ---- pass 1: this subsequence's dwords, rows <-> lane groups, 16 columns {64w + 16j + i} per j
+    c32 run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) run[r] = start[r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned a[4];
+#pragma unroll
+      for (int G = 0; G < 4; ++G) a[G] = L[G][j][r0];
+      auto s = __builtin_amdgcn_permlane32_swap(a[0], a[2], false, false);
+      a[0] = s[0]; a[2] = s[1];
+      s = __builtin_amdgcn_permlane32_swap(a[1], a[3], false, false);
+      a[1] = s[0]; a[3] = s[1];
+      s = __builtin_amdgcn_permlane16_swap(a[0], a[1], false, false);
+      a[0] = s[0]; a[1] = s[1];
+      s = __builtin_amdgcn_permlane16_swap(a[2], a[3], false, false);
+      a[2] = s[0]; a[3] = s[1];
+      mfma_f4 cr, ci;
+      mat.dft16(u32x4_t{a[0], a[1], a[2], a[3]}, cr, ci);
+      // column 16 n2 + n3 with n2 = 4w + j, n3 = i
+      const int rot = ((i >> 1) + g) & 3;
+      const int pos = (4 * w + j + 4 * rot) & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const c32 y = twiddle(cr[r], ci[r], run[r]);
+        img_a[((4 * g + r) * 16 + i) * 16 + pos] = T16::pack(y.x, y.y);
+        if (j < 3) run[r] = cmul(run[r], step[r]);
+      }
+    }
+    __syncthreads();
+    // ---- pass 2
+    u32x4_t frag[4];
+    {
+      const int gran = (g + (i >> 1) + w) & 3;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        frag[t] = *reinterpret_cast<const u32x4_t*>(&img_a[((4 * w + t) * 16 + i) * 16 + 4 * gran]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      mfma_f4 cr, ci;
+      mat.dft16(frag[t], cr, ci);
+      const int rot = (t + 2 * w + (t >> 1)) & 3;
+      const int pos = (i + 4 * rot) & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const c32 y = twiddle(cr[r], ci[r], t2[r]);
+        img_b[((4 * g + r) * 16 + 4 * w + t) * 16 + pos] = T16::pack(y.x, y.y);
+      }
+    }
+    __syncthreads();
+    // ---- pass 3
+    {
+      const int gran = (g + i + (i >> 1)) & 3;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        frag[t] = *reinterpret_cast<const u32x4_t*>(&img_b[((4 * w + t) * 16 + i) * 16 + 4 * gran]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      mfma_f4 cr, ci;
+      mat.dft16(frag[t], cr, ci);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) res[r0][t][r] = T16::pack(cr[r], ci[r]);
+    }
+  }
+
+  // ---- across the subsequences: twiddle W_N^(r0 k'), radix-R0 butterfly
+  c32 bu[R0][4];  // [r0][t] = W^(r0 (i + 64w + 1024g + 16t))
+  c32 v4[R0][4];  // [r0][r] = W^(256 r0 r)
+#pragma unroll
+  for (int r0 = 1; r0 < R0; ++r0) {
+    const c32 base = tw[(r0 * (i + 64 * w + 1024 * g)) & (N - 1)];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bu[r0][t] = t == 0 ? base : cmul(base, tw[16 * r0 * t]);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) v4[r0][r] = tw[256 * r0 * r];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c32 v[R0];
+      v[0] = T16::unpack(res[0][t][r]);
+#pragma unroll
+      for (int r0 = 1; r0 < R0; ++r0) {
+        const c32 f = T16::unpack(res[r0][t][r]);
+        const c32 tt = r == 0 ? bu[r0][t] : cmul(bu[r0][t], v4[r0][r]);
+        v[r0] = twiddle(f.x, f.y, tt);
+      }
+      if constexpr (R0 == 2) {
+        res[0][t][r] = T16::pack(v[0].x + v[1].x, v[0].y + v[1].y);
+        res[1][t][r] = T16::pack(v[0].x - v[1].x, v[0].y - v[1].y);
+      } else {
+        const c32 a = make_float2(v[0].x + v[2].x, v[0].y + v[2].y), b = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
+        const c32 c = make_float2(v[1].x + v[3].x, v[1].y + v[3].y), d = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
+        // forward: y1 = b - i d, y3 = b + i d; inverse the other way round
+        const c32 ym = make_float2(b.x + d.y, b.y - d.x), yp = make_float2(b.x - d.y, b.y + d.x);
+        res[0][t][r] = T16::pack(a.x + c.x, a.y + c.y);
+        res[2][t][r] = T16::pack(a.x - c.x, a.y - c.y);
+        res[1][t][r] = FWD ? T16::pack(ym.x, ym.y) : T16::pack(yp.x, yp.y);
+        res[3][t][r] = FWD ? T16::pack(yp.x, yp.y) : T16::pack(ym.x, ym.y);
+      }
+    }
+
+  // ---- blocks k0 out in natural order, two at a time through the two images
+  const int slot0 = mfma_out_slot<16>(i + 64 * w + 1024 * g);
+#pragma unroll
+  for (int k0 = 0; k0 < R0; k0 += 2) {
+    __syncthreads();  // the images' previous readers (pass 3, or the previous pair's stores) are done
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (h ? img_b : img_a)[slot0 + 16 * t + 260 * r] = res[k0 + h][t][r];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4_t* dst = out + tr * (N / 4) + (k0 + h) * 1024 + tid;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&(h ? img_b : img_a)[mfma_out_slot<16>(4 * (tid + 256 * q))]);
+        __builtin_nontemporal_store(v, dst + 256 * q);
+      }
+    }
   }
 }
 

@@ -32,8 +32,12 @@ bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
       if (mode == 3) mode = 0;
       else if (mode != 1 && mode != 2) return false;
       return entry_for<Plan4096, StoreBF16, true>(forward, mode, out);
-    case 8192: return entry_for<Plan8192Alt, StoreBF16, false, Plan8192>(forward, mode, out);
-    case 16384: return entry_for<Plan16384, StoreBF16, false, Plan16384Alt>(forward, mode, out);
+    case 8192:
+      if (mfma_big_entry_for<MfmaBF16Single, 2>(forward, mode, out)) return true;
+      return entry_for<Plan8192Alt, StoreBF16, false, Plan8192>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 16384:
+      if (mfma_big_entry_for<MfmaBF16Single, 4>(forward, mode, out)) return true;
+      return entry_for<Plan16384, StoreBF16, false, Plan16384Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
     default: return false;
   }
 }

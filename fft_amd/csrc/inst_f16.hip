@@ -36,8 +36,12 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
       else if (mode == 9) mode = 4;
       else if (mode != 1 && mode != 2) return false;
       return entry_for<Plan4096, StoreF16, true, Plan4096Mfma, Plan4096ResidentSplit>(forward, mode, out);
-    case 8192: return entry_for<Plan8192Alt, StoreF16, false, Plan8192>(forward, mode, out);
-    case 16384: return entry_for<Plan16384, StoreF16, false, Plan16384Alt>(forward, mode, out);
+    case 8192:
+      if (mfma_big_entry_for<MfmaF16, 2>(forward, mode, out)) return true;
+      return entry_for<Plan8192Alt, StoreF16, false, Plan8192>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 16384:
+      if (mfma_big_entry_for<MfmaF16, 4>(forward, mode, out)) return true;
+      return entry_for<Plan16384, StoreF16, false, Plan16384Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
     default: return false;
   }
 }

@@ -164,6 +164,42 @@ bool mfma_entry_for(bool forward, int mode, KernelEntry* out) {
   return false;
 }
 
+// N = 4096 R0 (8192, 16384), 16-bit storage: fft_mfma_big_kernel, one workgroup per transform.
+template <class T16, bool FWD, int R0, int MINW>
+void launch_mfma_big(const void* in, void* out, const float2* tw, long long batch, long long nchunks, unsigned grid,
+                     unsigned extra_lds, hipStream_t stream) {
+  (void)nchunks;
+  (void)grid;
+  (void)extra_lds;
+  fft_mfma_big_kernel<T16, FWD, R0, MINW><<<dim3((unsigned)batch), dim3(Mfma4096::WG), 0, stream>>>(
+      static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch);
+}
+
+template <class T16, bool FWD, int R0, int MINW>
+KernelEntry make_mfma_big_entry() {
+  KernelEntry e;
+  e.fn = reinterpret_cast<const void*>(&fft_mfma_big_kernel<T16, FWD, R0, MINW>);
+  e.launch = &launch_mfma_big<T16, FWD, R0, MINW>;
+  e.n = 4096 * R0;
+  e.threads = Mfma4096::WG;
+  e.tpb = 1;
+  e.e = 16 * R0;
+  e.radix[0] = R0;
+  e.radix[1] = 4096;
+  e.radix[2] = 1;
+  e.lds_bytes = 4 * 2 * mfma_out_words<16>();
+  return e;
+}
+
+template <class T16, int R0>
+bool mfma_big_entry_for(bool forward, int mode, KernelEntry* out) {
+  // R0 = 4 holds 16 + 16 packed results and inputs per subsequence: 168 VGPRs, three workgroups per CU
+  constexpr int MINW = R0 == 2 ? 4 : 3;
+  if (mode != 0) return false;
+  *out = forward ? make_mfma_big_entry<T16, true, R0, MINW>() : make_mfma_big_entry<T16, false, R0, MINW>();
+  return true;
+}
+
 // Defined one per translation unit (inst_*.hip) so the instantiations compile in parallel.
 // Returns false when (n, forward, mode) has no kernel for that storage type.
 bool lookup_f32_a(int n, bool forward, int mode, KernelEntry* out);  // 64 ... 1024

@@ -231,7 +231,8 @@ int tfft_initialize(int dtype, int n) {
 
   DevicePlan p;
   // n = 256 ... 4096: the table is followed by the lane-ordered tables of the matrix-core kernels
-  const bool mfma_tables = n >= 256 && n <= tfft::Mfma4096::N;
+  // (n = 8192, 16384 run 4096-point passes inside: the tables of n = 4096)
+  const bool mfma_tables = n >= 256;
   const size_t entries = (size_t)n + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (n == tfft::Mfma4096::N ? tfft::ConvMfma4096::TABLE : 0);
   std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
@@ -239,7 +240,7 @@ int tfft_initialize(int dtype, int n) {
     const double a = -2.0 * M_PI * (double)j / (double)n;
     h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
   }
-  if (mfma_tables) tfft::mfma_lane_tables(h.data() + n, n);
+  if (mfma_tables) tfft::mfma_lane_tables(h.data() + n, n < tfft::Mfma4096::N ? n : tfft::Mfma4096::N);
   if (n == tfft::Mfma4096::N) {
     tfft::conv_mfma4096_tables(h.data() + tfft::ConvMfma4096::OFFSET);
   }

@@ -278,6 +278,31 @@ def test_half_storage_matrix_core_lengths(oracle_mod, n, kind, mode):
                 assert worst <= TOL[kind], (n, mode, batch, forward, worst)
 
 
+@pytest.mark.parametrize("kind", ("fp16", "bf16"))
+@pytest.mark.parametrize("n", (8192, 16384))
+@pytest.mark.parametrize("mode", (0, 3, 4))
+def test_half_storage_matrix_core_long_lengths(oracle_mod, n, kind, mode):
+    """16-bit storage, N = 8192 and 16384: mode 0 (default) splits the transform into 2 or 4 interleaved
+    4096-point transforms on the matrix cores and combine them in registers; modes 3 and 4 are the fp32 VALU
+    kernels. Per-transform errors, both directions, out of place and in place."""
+    for batch in (1, 5, 531):
+        scale = 1.0 / np.sqrt(n) if kind == "fp16" else 1.0
+        x = (synth.uniform_complex(batch, n, seed=n + batch) * scale).astype(np.complex64)
+        for forward in (True, False):
+            for inplace in (False, True):
+                try:
+                    fft_amd.set_option("mode", mode)
+                    got, stored = run(x, kind, forward, inplace=inplace)
+                finally:
+                    fft_amd.set_option("mode", 0)
+                ref = oracle_mod.fft(stored, forward)
+                err = oracle_mod.rel_l2(got, ref)
+                assert err <= TOL[kind], f"{kind} n={n} mode={mode} batch={batch} forward={forward} rel_l2={err:.3e}"
+                step = max(1, batch // 61)
+                worst = max(oracle_mod.rel_l2(got[b], ref[b]) for b in list(range(0, batch, step)) + [batch - 1])
+                assert worst <= TOL[kind], (n, mode, batch, forward, worst)
+
+
 def test_matrix_core_tail_does_not_write_past_the_batch():
     n, batch, extra = 512, 13, 11  # 8 transforms per tile: the last tile is partial
     x = synth.uniform_complex(batch + extra, n, seed=5) / np.sqrt(n)
