@@ -77,12 +77,16 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *                          workgroup per signal, which measured faster)
  *   "extra_lds"          : bytes of unused dynamic LDS per workgroup, to lower occupancy
  *   "grid_blocks_per_cu" also sizes the grid of kernels that are resident by default (16-bit storage,
- *                          n = 4096: three workgroups per CU).
+ *                          n = 512, 1024, 2048: three workgroups per CU).
  *   "mode"               : 0 = default kernel; 1 = load/store only, 2 = no LDS exchange (both give wrong
  *                          results on purpose; they price the memory pattern and the butterflies);
  *                          3 and up = the alternative kernels of a (dtype, n) kept for A/B timing (another
- *                          factorisation or workgroup size; for 16-bit storage at n = 4096, mode 3 is the
- *                          fp32-VALU kernel and 5-8 other forms of the matrix-core kernel). A mode a length
+ *                          factorisation or workgroup size). 16-bit storage at n >= 256 runs on the matrix
+ *                          cores by default; there mode 3 (and 4) are the fp32-VALU kernels and 5-12 other
+ *                          forms of the matrix-core kernel: 6 = one workgroup per tile with the twiddle
+ *                          table, 10 = one workgroup per tile with incrementally built twiddles, 11 =
+ *                          resident grid, 12 = mode 10 with one LDS image (n <= 4096); 5, 7 = one LDS image
+ *                          (n = 4096); 8 = split bf16 matrix (bf16, n = 4096). A mode a length
  *                          does not have returns TFFT_ERR_UNSUPPORTED. For the convolution entry points
  *                          mode 3 selects the fp32-VALU kernels for fp16 storage.
  *   "sync"               : 1 = synchronise the stream after every launch like the reference */

@@ -67,6 +67,7 @@ def test_half_storage_vs_oracle(oracle_mod, n, kind):
         got, stored = run(x, kind, forward)
         ref = oracle_mod.fft(stored, forward)
         err = oracle_mod.rel_l2(got, ref)
+        print(f"{kind} n={n} forward={forward} rel_l2={err:.3e}")
         assert err <= TOL[kind], f"{kind} n={n} forward={forward} rel_l2={err:.3e}"
 
 
