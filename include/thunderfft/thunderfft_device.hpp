@@ -8,8 +8,11 @@
 //     ThunderFFT_smem2gmem      (and the direct ThunderFFT_gmem2reg / ThunderFFT_reg2gmem, :55-65)
 // The reference stages rows through shared memory into mma.m16n8k8 fragments. On wave64 hardware a
 // thread's points go from global memory straight into VGPRs in the order its first butterfly pass
-// wants them, so the shared-memory staging calls have no counterpart: the three calls below are
-// the whole pipeline, and LDS is only the transform's internal exchange buffer (`workspace`).
+// wants them, so gmem2reg -> kernel_reg -> reg2gmem is the fast pipeline and LDS is only the
+// transform's internal exchange buffer (`workspace`). The staged calls exist as well, for kernels that
+// want the block's signals or spectra in natural order in LDS (work across bins or across transforms,
+// lengths whose transforms do not chain in registers): `smem` is [batch_per_block<N>][N] elements of
+// vec2_t<T>, natural order, smem_bytes<T, N> bytes, separate from `workspace`.
 //
 //   template <int N> __global__ __launch_bounds__(thunderfft::block_threads<N>)
 //   void my_kernel(const float2* in, float2* out, const float2* tw, int batch) {
@@ -106,6 +109,66 @@ template <int N, bool forward>
 __device__ __forceinline__ void ThunderFFT_kernel_reg(const DeviceFFT<N>& fft, float2 (&reg)[elements_per_thread<N>],
                                                       bool lead = true) {
   fft.template transform<forward>(reg, lead);
+}
+
+// ---- staged pipeline -------------------------------------------------------------------------
+template <typename T, int N> inline constexpr int smem_bytes = (int)sizeof(vec2_t<T>) * N * batch_per_block<N>;
+
+namespace detail {
+__device__ __forceinline__ float2 widen(float2 v) { return v; }
+__device__ __forceinline__ float2 widen(__half2 v) { return __half22float2(v); }
+__device__ __forceinline__ float2 widen(__hip_bfloat162 v) { return __bfloat1622float2(v); }
+template <typename T> __device__ __forceinline__ vec2_t<T> narrow(float2 v);
+template <> __device__ __forceinline__ float2 narrow<float>(float2 v) { return v; }
+template <> __device__ __forceinline__ __half2 narrow<__half>(float2 v) { return __float22half2_rn(v); }
+template <> __device__ __forceinline__ __hip_bfloat162 narrow<__hip_bfloat16>(float2 v) { return __float22bfloat162_rn(v); }
+}  // namespace detail
+
+// Global memory -> LDS, all threads of the block (reference: ThunderFFT_gmem2smem, thunderfft.cuh:68-71):
+// the block's batch_per_block<N> transforms in natural order, 16 bytes per thread and step; transforms
+// numbered `valid` and above are filled with zeros. Follow with __syncthreads().
+template <typename T, int N>
+__device__ __forceinline__ void ThunderFFT_gmem2smem(vec2_t<T>* smem, const vec2_t<T>* __restrict__ gmem,
+                                                     int valid = batch_per_block<N>) {
+  constexpr int PER = 16 / (int)sizeof(vec2_t<T>);                 // elements per 16-byte granule
+  constexpr int GRANULES = N * batch_per_block<N> / PER;
+  const tfft::u32x4_t* src = reinterpret_cast<const tfft::u32x4_t*>(gmem);
+  tfft::u32x4_t* dst = reinterpret_cast<tfft::u32x4_t*>(smem);
+  for (int q = threadIdx.x; q < GRANULES; q += block_threads<N>)
+    dst[q] = (q * PER < valid * N) ? __builtin_nontemporal_load(src + q) : tfft::u32x4_t{0u, 0u, 0u, 0u};
+}
+
+// LDS -> global memory (reference: ThunderFFT_smem2gmem, thunderfft.cuh:74-77); transforms numbered
+// `valid` and above are not written. Call after a __syncthreads() that follows the last LDS write.
+template <typename T, int N>
+__device__ __forceinline__ void ThunderFFT_smem2gmem(vec2_t<T>* __restrict__ gmem, const vec2_t<T>* smem,
+                                                     int valid = batch_per_block<N>) {
+  constexpr int PER = 16 / (int)sizeof(vec2_t<T>);
+  constexpr int GRANULES = N * batch_per_block<N> / PER;
+  const tfft::u32x4_t* src = reinterpret_cast<const tfft::u32x4_t*>(smem);
+  tfft::u32x4_t* dst = reinterpret_cast<tfft::u32x4_t*>(gmem);
+  for (int q = threadIdx.x; q < GRANULES; q += block_threads<N>)
+    if (q * PER < valid * N) __builtin_nontemporal_store(src[q], dst + q);
+}
+
+// LDS -> register file in the order the transform wants (reference: ThunderFFT_smem2reg,
+// thunderfft.cuh:80-83): reg[e] = point fft.index_in(e) of transform fft.transform_in(e).
+template <typename T, int N>
+__device__ __forceinline__ void ThunderFFT_smem2reg(const DeviceFFT<N>& fft, float2 (&reg)[elements_per_thread<N>],
+                                                    const vec2_t<T>* smem) {
+#pragma unroll
+  for (int e = 0; e < elements_per_thread<N>; ++e) reg[e] = detail::widen(smem[fft.transform_in(e) * N + fft.index_in(e)]);
+}
+
+// Register file -> LDS in natural order (reference: ThunderFFT_reg2smem, thunderfft.cuh:86-89):
+// reg[e] is bin fft.index_out(e) of transform fft.transform_out(e). Every thread must be past its
+// last read of `smem` (a __syncthreads() after smem2reg; ThunderFFT_kernel_reg contains one).
+template <typename T, int N>
+__device__ __forceinline__ void ThunderFFT_reg2smem(const DeviceFFT<N>& fft, vec2_t<T>* smem,
+                                                    const float2 (&reg)[elements_per_thread<N>]) {
+#pragma unroll
+  for (int e = 0; e < elements_per_thread<N>; ++e)
+    smem[fft.transform_out(e) * N + fft.index_out(e)] = detail::narrow<T>(reg[e]);
 }
 
 // Device address of the table ThunderFFTInitialize<T>(N) built on the current device.
