@@ -8,7 +8,14 @@
 // compute_ms is the reference's second figure (util/helper.h:122-141, baseline/thunderfft_bench.h:7-55):
 // a kernel that loads once, runs the register-resident transform R times and stores once is timed
 // at R and 2R in-kernel repeats, compute_ms = (t(2R) - t(R)) / R -- the cost of one transform pass
-// over the batch with HBM taken out. Built on the device-level API; fp32 storage only.
+// over the batch with HBM taken out. Built on the device-level API; fp32 storage only. The row
+// thunderfft_s is the reference's shared-memory variant (baseline/thunderfft_bench.h:139-261): the block's
+// signals stay in LDS in natural order and every repeat is smem2reg, transform, reg2smem; its e2e_ms is one
+// pass gmem2smem ... smem2gmem (N <= 8192, where the staging buffer and the workspace fit in LDS).
+//
+// Compile-time defaults in the manner of the reference's profiling build (sample/bench/main.cu:12-26):
+// -DTHUNDERFFT_PROFILE_N=1024 -DTHUNDERFFT_PROFILE_BATCH=65536 -DTHUNDERFFT_PROFILE_HALF=1 preset --n,
+// --points (N x batch) and --dtype fp16; the command line still overrides them.
 //
 // Usage: tfft_bench [--n 256,4096] [--points 268435456] [--runs 10] [--input sine|hash]
 //                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--extra-lds BYTES] [--csv] [--ndjson]
@@ -81,6 +88,53 @@ void launch_benchmark_reg(float2* data, long long batch, unsigned repeats, hipSt
       data, data, tw, batch, repeats);
 }
 
+// The reference's ThunderFFT_benchmark_smem (baseline/thunderfft_bench.h:139-182).
+template <int N>
+__global__ __launch_bounds__(thunderfft::block_threads<N>) void benchmark_smem_kernel(const float2* __restrict__ in,
+                                                                                       float2* __restrict__ out,
+                                                                                       const float2* __restrict__ tw,
+                                                                                       long long batch, unsigned inside_repeats) {
+  constexpr int BPB = thunderfft::batch_per_block<N>;
+  __shared__ __attribute__((aligned(16))) char workspace[thunderfft::workspace_bytes<N>];
+  __shared__ __attribute__((aligned(16))) float2 stage[N * BPB];
+  thunderfft::DeviceFFT<N> fft(tw, workspace);
+  const long long first = (long long)blockIdx.x * BPB;
+  const int valid = (int)((batch - first < BPB) ? batch - first : BPB);
+  float2 reg[thunderfft::elements_per_thread<N>];
+  thunderfft::ThunderFFT_gmem2smem<float, N>(stage, in + first * N, valid);
+  __syncthreads();
+#pragma unroll 1
+  for (unsigned i = 0; i < inside_repeats; ++i) {
+    thunderfft::ThunderFFT_smem2reg<float, N>(fft, reg, stage);
+    thunderfft::ThunderFFT_kernel_reg<N, true>(fft, reg, true);
+    thunderfft::ThunderFFT_reg2smem<float, N>(fft, stage, reg);
+    __syncthreads();
+  }
+  thunderfft::ThunderFFT_smem2gmem<float, N>(out + first * N, stage, valid);
+}
+
+template <int N>
+void launch_benchmark_smem(float2* data, long long batch, unsigned repeats, hipStream_t s) {
+  constexpr int BPB = thunderfft::batch_per_block<N>;
+  const float2* tw = thunderfft::twiddle_table<float>(N);
+  benchmark_smem_kernel<N><<<dim3((unsigned)((batch + BPB - 1) / BPB)), dim3(thunderfft::block_threads<N>), 0, s>>>(
+      data, data, tw, batch, repeats);
+}
+
+bool launch_benchmark_smem_n(int n, float2* data, long long batch, unsigned repeats, hipStream_t s) {
+  switch (n) {
+    case 64: launch_benchmark_smem<64>(data, batch, repeats, s); return true;
+    case 128: launch_benchmark_smem<128>(data, batch, repeats, s); return true;
+    case 256: launch_benchmark_smem<256>(data, batch, repeats, s); return true;
+    case 512: launch_benchmark_smem<512>(data, batch, repeats, s); return true;
+    case 1024: launch_benchmark_smem<1024>(data, batch, repeats, s); return true;
+    case 2048: launch_benchmark_smem<2048>(data, batch, repeats, s); return true;
+    case 4096: launch_benchmark_smem<4096>(data, batch, repeats, s); return true;
+    case 8192: launch_benchmark_smem<8192>(data, batch, repeats, s); return true;
+    default: return false;
+  }
+}
+
 bool launch_benchmark_reg_n(int n, float2* data, long long batch, unsigned repeats, hipStream_t s) {
   switch (n) {
     case 64: launch_benchmark_reg<64>(data, batch, repeats, s); return true;
@@ -96,12 +150,27 @@ bool launch_benchmark_reg_n(int n, float2* data, long long batch, unsigned repea
   }
 }
 
+#ifdef THUNDERFFT_PROFILE_N
+#ifndef THUNDERFFT_PROFILE_BATCH
+#define THUNDERFFT_PROFILE_BATCH 65536
+#endif
+#endif
+
 struct Args {
+#ifdef THUNDERFFT_PROFILE_N
+  std::vector<int> ns = {THUNDERFFT_PROFILE_N};
+  long long points = (long long)(THUNDERFFT_PROFILE_N) * (THUNDERFFT_PROFILE_BATCH);
+#else
   std::vector<int> ns = {256, 512, 1024, 2048, 4096, 8192, 16384};
   long long points = 1ll << 28;
+#endif
   int runs = 10;
   std::string input = "hash";
+#if defined(THUNDERFFT_PROFILE_HALF) && THUNDERFFT_PROFILE_HALF
+  std::string dtype = "fp16";
+#else
   std::string dtype = "fp32";
+#endif
   int inplace = 1;
   int mode = 0;
   int grid = 0;
@@ -285,6 +354,16 @@ void run_one(const Args& a, int n) {
   const double bpp = 2.0 * sizeof(vec2_t<T>);
   push_row(std::string("thunderfft(") + a.dtype + (a.mode ? ",mode" + std::to_string(a.mode) : "") + ")", n, radix.str(),
            batch, err, ms, bpp, compute_ms);
+  if constexpr (std::is_same_v<T, float>) {
+    if (a.inside_repeats > 0 && n <= 8192) {
+      const unsigned R = (unsigned)a.inside_repeats;
+      float2* buf = reinterpret_cast<float2*>(d_perf);
+      const float e2e_s = time_ms(s, 1, a.runs, [&] { launch_benchmark_smem_n(n, buf, batch, 1, s); });
+      const float t_r = time_ms(s, 1, 1, [&] { launch_benchmark_smem_n(n, buf, batch, R, s); });
+      const float t_2r = time_ms(s, 1, 1, [&] { launch_benchmark_smem_n(n, buf, batch, 2 * R, s); });
+      push_row("thunderfft_s(fp32)", n, radix.str(), batch, NAN, e2e_s, bpp, ((double)t_2r - (double)t_r) / (double)R);
+    }
+  }
   if (hipfft_ms > 0) push_row("hipfft(fp32)", n, "-", batch, 0.0, hipfft_ms, 16.0);
   {
     const size_t bytes = sizeof(vec2_t<T>) * total;

@@ -69,9 +69,14 @@ def test_fft_sample_report():
 def test_tfft_bench_sinks():
     out = run("tfft_bench", "--n", "256,4096", "--points", 1 << 22, "--runs", 2, "--ndjson", "--inside-repeats", 4)
     rows = [json.loads(line) for line in out.splitlines() if line.startswith("{")]
-    ours = [r for r in rows if r["type"].startswith("thunderfft")]
+    ours = [r for r in rows if r["type"].startswith("thunderfft(")]
     assert [r["N"] for r in ours] == [256, 4096]
     for r in ours:
         assert r["max_abs_err"] < 1e-3 and r["e2e_ms"] > 0 and r["compute_ms"] > 0 and r["gflops"] > 0
+    # the shared-memory variant of the reference's bench (baseline/thunderfft_bench.h:139-261): staged device calls
+    staged = [r for r in rows if r["type"].startswith("thunderfft_s(")]
+    assert [r["N"] for r in staged] == [256, 4096]
+    for r in staged:
+        assert r["e2e_ms"] > 0 and r["compute_ms"] > 0
     out = run("tfft_bench", "--n", "1024", "--points", 1 << 20, "--runs", 2, "--csv")
     assert out.splitlines()[0] == "type,N,radix,B,max_abs_err,compute_ms,e2e_ms,gflops,gbps,hbm_frac"
