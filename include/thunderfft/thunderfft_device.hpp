@@ -171,6 +171,67 @@ __device__ __forceinline__ void ThunderFFT_reg2smem(const DeviceFFT<N>& fft, vec
     smem[fft.transform_out(e) * N + fft.index_out(e)] = detail::narrow<T>(reg[e]);
 }
 
+// ---- layout-aware staging (reference: layout_t, thunderfft.cuh:11-33, and the sL parameter of its staging calls)
+// Element i of signal j lives at idx = i * elem_stride + j * batch_stride, and every pad_period elements are
+// followed by `pad` unused ones: slot = idx + (idx / pad_period) * pad. `reversed` (input already in the
+// digit-reversed order of the reference's fragment maps) has no meaning for these register maps.
+template <int N_, int Batch_, int ElemStride_, int BatchStride_, int PadPeriod_, int Pad_, bool Reversed_ = false>
+struct layout_t {
+  static constexpr int N = N_;
+  static constexpr int batch = Batch_;
+  static constexpr int elem_stride = ElemStride_;
+  static constexpr int batch_stride = BatchStride_;
+  static constexpr int pad_period = PadPeriod_;
+  static constexpr int pad = Pad_;
+  static constexpr bool reversed = Reversed_;
+  static_assert(!Reversed_, "registers take natural-order input here");
+  static_assert(PadPeriod_ > 0, "pad_period");
+  __host__ __device__ static constexpr int slot(int i, int j) {
+    const int idx = i * elem_stride + j * batch_stride;
+    return idx + (idx / pad_period) * pad;
+  }
+  // elements the array needs
+  static constexpr int slots = slot(N_ - 1, Batch_ - 1) + 1;
+};
+template <int N>
+using natural_layout = layout_t<N, batch_per_block<N>, 1, N, N * batch_per_block<N>, 0, false>;
+// The layouts the bench uses (reference: bench_layout, thunderfft_layout_tuned.h:6-97, tuned pads per length).
+// The register maps here read and write an unpadded natural-order array without bank conflicts (a thread's
+// points are N / R apart, neighbouring lanes hold neighbouring points), so both are the natural layout.
+template <typename T, int N, int BPB = batch_per_block<N>>
+struct bench_layout {
+  using L_in = layout_t<N, BPB, 1, N, N * BPB, 0, false>;
+  using L_out = L_in;
+};
+
+template <typename T, typename sL>
+__device__ __forceinline__ void ThunderFFT_gmem2smem(vec2_t<T>* smem, const vec2_t<T>* __restrict__ gmem,
+                                                     int valid = sL::batch) {
+  static_assert(sL::batch == batch_per_block<sL::N>, "one layout per workgroup tile");
+  for (int q = threadIdx.x; q < sL::N * sL::batch; q += block_threads<sL::N>)
+    smem[sL::slot(q % sL::N, q / sL::N)] = q < valid * sL::N ? gmem[q] : detail::narrow<T>(make_float2(0.f, 0.f));
+}
+template <typename T, typename sL>
+__device__ __forceinline__ void ThunderFFT_smem2gmem(vec2_t<T>* __restrict__ gmem, const vec2_t<T>* smem,
+                                                     int valid = sL::batch) {
+  for (int q = threadIdx.x; q < sL::N * sL::batch; q += block_threads<sL::N>)
+    if (q < valid * sL::N) gmem[q] = smem[sL::slot(q % sL::N, q / sL::N)];
+}
+template <typename T, typename sL>
+__device__ __forceinline__ void ThunderFFT_smem2reg(const DeviceFFT<sL::N>& fft, float2 (&reg)[elements_per_thread<sL::N>],
+                                                    const vec2_t<T>* smem) {
+#pragma unroll
+  for (int e = 0; e < elements_per_thread<sL::N>; ++e)
+    reg[e] = detail::widen(smem[sL::slot(fft.index_in(e), fft.transform_in(e))]);
+}
+template <typename T, typename sL>
+__device__ __forceinline__ void ThunderFFT_reg2smem(const DeviceFFT<sL::N>& fft, vec2_t<T>* smem,
+                                                    const float2 (&reg)[elements_per_thread<sL::N>]) {
+#pragma unroll
+  for (int e = 0; e < elements_per_thread<sL::N>; ++e)
+    smem[sL::slot(fft.index_out(e), fft.transform_out(e))] = detail::narrow<T>(reg[e]);
+}
+
 // Device address of the table ThunderFFTInitialize<T>(N) built on the current device.
 template <typename T>
 inline const float2* twiddle_table(int N) {

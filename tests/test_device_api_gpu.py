@@ -61,11 +61,13 @@ def test_user_kernel_band_stop(oracle_mod, user_lib, dtype, n, tol):
 
 
 @pytest.mark.parametrize("dtype,n,tol", [("fp32", 64, 1e-5), ("fp32", 512, 1e-5), ("fp32", 2048, 1e-5),
-                                          ("fp32", 4096, 1e-5), ("fp16", 1024, 1e-2)])
+                                          ("fp32", 4096, 1e-5), ("fp16", 1024, 1e-2),
+                                          ("fp32", 128, 1e-5), ("fp32", 1024, 1e-5), ("fp16", 256, 1e-2)])
 def test_user_kernel_band_stop_staged(oracle_mod, user_lib, dtype, n, tol):
     """The staged pipeline gmem2smem -> smem2reg -> kernel_reg -> reg2smem -> smem2gmem (the reference's
     thunderfft.cuh:68-89 calls): the spectrum visits LDS in natural order, so lengths whose transforms do not
-    chain in registers (512, 2048) work too."""
+    chain in registers (512, 2048) work too. The last three cases use a padded layout_t (thunderfft.cuh:11-33)
+    through the layout-aware overloads."""
     batch = 3 * max(1, 2048 // n) + 1
     lo, hi = n // 8, n // 2 + 3
     x = synth.uniform_complex(batch, n, seed=n + 1)
