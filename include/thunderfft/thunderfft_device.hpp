@@ -60,6 +60,8 @@ template <> struct device_io<float> { using type = tfft::StoreF32; };
 template <> struct device_io<__half> { using type = tfft::StoreF16; };
 template <> struct device_io<__hip_bfloat16> { using type = tfft::StoreBF16; };
 
+using tfft::cmul;  // complex product of two float2 (reference: cmul, detail/util_arith.h:39-50)
+
 // One workgroup's transform state: per-thread index maps, twiddle bases, the LDS workspace.
 template <int N>
 using DeviceFFT = tfft::BlockFFT<typename device_plan<N>::type>;
@@ -67,7 +69,9 @@ using DeviceFFT = tfft::BlockFFT<typename device_plan<N>::type>;
 // Launch geometry of a user kernel (reference: threads_per_warp * warp_per_block<N>,
 // batch_per_block<N>, the `ept` of its samples and the shared-memory size,
 // detail/thunderfft_impl.cuh:14-32, sample/conv1d/conv1d_fullfft_l4096_thunder.cu:25-27, 394).
+inline constexpr int threads_per_warp = 64;  // wave64
 template <int N> inline constexpr int block_threads = device_plan<N>::type::WG;
+template <int N> inline constexpr int warp_per_block = device_plan<N>::type::WG / threads_per_warp;
 template <int N> inline constexpr int batch_per_block = device_plan<N>::type::TPB;
 template <int N> inline constexpr int elements_per_thread = device_plan<N>::type::E;
 template <int N> inline constexpr int workspace_bytes = device_plan<N>::type::LDS_BYTES;
