@@ -52,6 +52,22 @@ inline void conv_mfma4096_tables(float2* dst) {
 
 enum : int { kConvMfmaComplex = 0, kConvMfmaRealIn = 1, kConvMfmaRealPair = 2 };
 
+// Complex products on packed fp16 (v_pk_mul_f16 + v_pk_fma_f16, half swaps and signs as operand
+// modifiers): the pass-2 twiddles and the filter product take 3 instructions per value, rounding
+// included, where fp32 arithmetic takes 4 to 7. The kernel is bound by VALU issue, and the values are
+// rounded to fp16 right afterwards anyway; the reference multiplies in half2 throughout
+// (thunderfft/include/thunderfft/detail/util_arith.h:65-73).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2_t pack_h2(float re, float im) {
+  return __builtin_convertvector(f32x2_t{re, im}, h2_t);  // one v_cvt_pk_f16_f32, round to nearest even
+}
+template <bool CONJ>
+__device__ __forceinline__ unsigned cmul_h2(h2_t x, h2_t t) {  // x * t, or x * conj(t)
+  const h2_t a = x * t.xx;
+  const h2_t xs = CONJ ? h2_t{x.y, -x.x} : h2_t{-x.y, x.x};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_fma(xs, t.yy, a));
+}
+
 // One direction's constants: the DFT-16 matrix fragments and the pass-2 twiddles of this lane.
 template <bool FWD>
 struct MfmaDir {
@@ -99,7 +115,7 @@ __device__ __forceinline__ void mfma_pass1(const MfmaDir<FWD>& d, const u32x4_t 
 
 // Pass 2: image `src` (rows (k1, n3), points n2) to image `dst` (rows (k2, k1), points n3).
 template <bool FWD>
-__device__ __forceinline__ void mfma_pass2(const MfmaDir<FWD>& d, const c32 (&t2)[4], const unsigned* src, unsigned* dst,
+__device__ __forceinline__ void mfma_pass2(const MfmaDir<FWD>& d, const h2_t (&t2)[4], const unsigned* src, unsigned* dst,
                                            int w, int g, int i) {
   const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
   u32x4_t frag[4];
@@ -115,10 +131,8 @@ __device__ __forceinline__ void mfma_pass2(const MfmaDir<FWD>& d, const c32 (&t2
     const int rot = (t + 2 * w + (t >> 1)) & 3;
     const int pos = (i + 4 * rot) & 15;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const c32 y = MfmaDir<FWD>::twiddle(cr[r], ci[r], t2[r]);
-      dst[((4 * g + r) * 16 + 4 * w + t) * 16 + pos] = pack_f16(y.x, y.y);
-    }
+    for (int r = 0; r < 4; ++r)
+      dst[((4 * g + r) * 16 + 4 * w + t) * 16 + pos] = cmul_h2<!FWD>(pack_h2(cr[r], ci[r]), t2[r]);
   }
 }
 
@@ -234,14 +248,14 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
     step_c[2 * h] = make_float2(q.x, q.y);
     step_c[2 * h + 1] = make_float2(q.z, q.w);
   }
-  c32 t2[4];
+  h2_t t2[4];
   {
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
     const u32x4_t p = ftab[128], q = ftab[192];
-    t2[0] = make_float2(__uint_as_float(p.x), __uint_as_float(p.y));
-    t2[1] = make_float2(__uint_as_float(p.z), __uint_as_float(p.w));
-    t2[2] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
-    t2[3] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
+    t2[0] = pack_h2(__uint_as_float(p.x), __uint_as_float(p.y));
+    t2[1] = pack_h2(__uint_as_float(p.z), __uint_as_float(p.w));
+    t2[2] = pack_h2(__uint_as_float(q.x), __uint_as_float(q.y));
+    t2[3] = pack_h2(__uint_as_float(q.z), __uint_as_float(q.w));
   }
   MfmaDir<true> fwd;
   MfmaDir<false> inv;
@@ -287,13 +301,8 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned hw = hreg[t][r];
-        const float2 hf = __half22float2(*reinterpret_cast<const __half2*>(&hw));
-        const float re = xr[t][r] * hf.x - xi[t][r] * hf.y;
-        const float im = xr[t][r] * hf.y + xi[t][r] * hf.x;
-        packed[t][r] = pack_f16(re, im);
-      }
+      for (int r = 0; r < 4; ++r)
+        packed[t][r] = cmul_h2<false>(pack_h2(xr[t][r], xi[t][r]), __builtin_bit_cast(h2_t, (unsigned)hreg[t][r]));
     }
 
     // ---- inverse transform (image a is free: every wave is past the barrier that followed its reads)
