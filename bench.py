@@ -184,7 +184,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            # fp32 storage: fp32 VALU arithmetic; 16-bit storage at N = 4096: 16-bit matrix-core operands, fp32 accumulation
+            # fp32 storage: fp32 VALU arithmetic; 16-bit storage at N >= 256: 16-bit matrix-core operands, fp32 accumulation
             "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.dtype],
             "data": "synthetic",
             "config": {
@@ -203,7 +203,8 @@ def main():
                 "traffic": recorded_traffic(f"fft_lds_kernel_f32_n{n}_b{batch}") if args.dtype == "fp32"
                 else recorded_traffic(f"fft_kernel_{args.dtype}_n{n}_b{batch}"),
                 "kernel": f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>" if args.dtype == "fp32"
-                else (f"tfft::fft_mfma4096_kernel<{args.dtype}, forward>" if n == 4096
+                else (f"tfft::fft_mfma4096_kernel<{args.dtype}, forward, N={n}>" if 256 <= n <= 4096
+                      else f"tfft::fft_mfma_big_kernel<{args.dtype}, forward, N={n}>" if n > 4096
                       else f"tfft::fft_lds_kernel<Plan{n}, {args.dtype} storage, forward>"),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -230,10 +230,11 @@ int tfft_initialize(int dtype, int n) {
   if (g_plans.count(key)) return TFFT_OK;
 
   DevicePlan p;
-  // n = 256 ... 4096: the table is followed by the lane-ordered tables of the matrix-core kernels
+  // 16-bit storage, n >= 256: the table is followed by the lane-ordered tables of the matrix-core kernels
   // (n = 8192, 16384 run 4096-point passes inside: the tables of n = 4096)
-  const bool mfma_tables = n >= 256;
-  const size_t entries = (size_t)n + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (n == tfft::Mfma4096::N ? tfft::ConvMfma4096::TABLE : 0);
+  const bool mfma_tables = dtype != TFFT_F32 && n >= 256;
+  const bool conv_tables = mfma_tables && n == tfft::Mfma4096::N;
+  const size_t entries = (size_t)n + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (conv_tables ? tfft::ConvMfma4096::TABLE : 0);
   std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
     // exact reduction of the angle: j/n is a dyadic rational, evaluated in fp64 and rounded once
@@ -241,7 +242,7 @@ int tfft_initialize(int dtype, int n) {
     h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
   }
   if (mfma_tables) tfft::mfma_lane_tables(h.data() + n, n < tfft::Mfma4096::N ? n : tfft::Mfma4096::N);
-  if (n == tfft::Mfma4096::N) {
+  if (conv_tables) {
     tfft::conv_mfma4096_tables(h.data() + tfft::ConvMfma4096::OFFSET);
   }
   TFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p.tw), sizeof(float2) * entries));
