@@ -52,22 +52,6 @@ inline void conv_mfma4096_tables(float2* dst) {
 
 enum : int { kConvMfmaComplex = 0, kConvMfmaRealIn = 1, kConvMfmaRealPair = 2 };
 
-// Complex products on packed fp16 (v_pk_mul_f16 + v_pk_fma_f16, half swaps and signs as operand
-// modifiers): the pass-2 twiddles and the filter product take 3 instructions per value, rounding
-// included, where fp32 arithmetic takes 4 to 7. The kernel is bound by VALU issue, and the values are
-// rounded to fp16 right afterwards anyway; the reference multiplies in half2 throughout
-// (thunderfft/include/thunderfft/detail/util_arith.h:65-73).
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ h2_t pack_h2(float re, float im) {
-  return __builtin_convertvector(f32x2_t{re, im}, h2_t);  // one v_cvt_pk_f16_f32, round to nearest even
-}
-template <bool CONJ>
-__device__ __forceinline__ unsigned cmul_h2(h2_t x, h2_t t) {  // x * t, or x * conj(t)
-  const h2_t a = x * t.xx;
-  const h2_t xs = CONJ ? h2_t{x.y, -x.x} : h2_t{-x.y, x.x};
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_fma(xs, t.yy, a));
-}
-
 // One direction's constants: the DFT-16 matrix fragments and the pass-2 twiddles of this lane.
 template <bool FWD>
 struct MfmaDir {

@@ -201,6 +201,21 @@ __device__ __forceinline__ unsigned pack_f16(float re, float im) {
   return *reinterpret_cast<const unsigned*>(&h);
 }
 
+// Complex products on packed fp16 (v_pk_mul_f16 + v_pk_fma_f16, half swaps and signs as operand
+// modifiers): the pass-2 twiddles and the filter product take 3 instructions per value, rounding
+// included, where fp32 arithmetic takes 4 to 7. The values are rounded to fp16 right afterwards anyway;
+// the reference multiplies in half2 throughout (thunderfft/include/thunderfft/detail/util_arith.h:65-73).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2_t pack_h2(float re, float im) {
+  return __builtin_convertvector(f32x2_t{re, im}, h2_t);  // one v_cvt_pk_f16_f32, round to nearest even
+}
+template <bool CONJ>
+__device__ __forceinline__ unsigned cmul_h2(h2_t x, h2_t t) {  // x * t, or x * conj(t)
+  const h2_t a = x * t.xx;
+  const h2_t xs = CONJ ? h2_t{x.y, -x.x} : h2_t{-x.y, x.x};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_fma(xs, t.yy, a));
+}
+
 typedef __bf16 mfma_bf8 __attribute__((ext_vector_type(8)));
 
 // The 16-point DFT of 16 columns on the matrix cores for one 16-bit storage type: this lane's rows of
@@ -232,6 +247,11 @@ struct MfmaF16 {
   }
   static __device__ __forceinline__ unsigned pack(float re_, float im_) { return pack_f16(re_, im_); }
   static __device__ __forceinline__ c32 unpack(unsigned v) { return __half22float2(*reinterpret_cast<const __half2*>(&v)); }
+  // pass-2 twiddles: kept and applied as packed fp16
+  using tw2_t = h2_t;
+  static __device__ __forceinline__ tw2_t make_tw2(c32 t) { return pack_h2(t.x, t.y); }
+  template <bool FWD>
+  static __device__ __forceinline__ unsigned twiddle_pack(float re_, float im_, tw2_t t) { return cmul_h2<!FWD>(pack_h2(re_, im_), t); }
 };
 
 template <bool SPLIT>
@@ -267,6 +287,14 @@ struct MfmaBF16T {
   }
   static __device__ __forceinline__ unsigned pack(float re_, float im_) { return StoreBF16::cvt(make_float2(re_, im_)); }
   static __device__ __forceinline__ c32 unpack(unsigned v) { return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)); }
+  // pass-2 twiddles: fp32 (8 mantissa bits would not carry a twiddle)
+  using tw2_t = c32;
+  static __device__ __forceinline__ tw2_t make_tw2(c32 t) { return t; }
+  template <bool FWD>
+  static __device__ __forceinline__ unsigned twiddle_pack(float re_, float im_, tw2_t t) {
+    const c32 y = FWD ? make_float2(re_ * t.x - im_ * t.y, re_ * t.y + im_ * t.x) : make_float2(re_ * t.x + im_ * t.y, im_ * t.x - re_ * t.y);
+    return pack(y.x, y.y);
+  }
 };
 using MfmaBF16 = MfmaBF16T<true>;
 using MfmaBF16Single = MfmaBF16T<false>;
@@ -348,13 +376,13 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   mat.init(tabs, FWD, tid & 63);
   T16 mat1 = mat;  // pass 1: DFT_16 when R1 = 16, else I (x) DFT_R1
   if constexpr (R1 > 1 && R1 < 16) mat1.init_pass1(tabs, FWD, tid & 63);
-  c32 t2[4];
+  typename T16::tw2_t t2[4];
   {
     const u32x4_t p = ftab[128], q = ftab[192];
-    t2[0] = make_float2(__uint_as_float(p.x), __uint_as_float(p.y));
-    t2[1] = make_float2(__uint_as_float(p.z), __uint_as_float(p.w));
-    t2[2] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
-    t2[3] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
+    t2[0] = T16::make_tw2(make_float2(__uint_as_float(p.x), __uint_as_float(p.y)));
+    t2[1] = T16::make_tw2(make_float2(__uint_as_float(p.z), __uint_as_float(p.w)));
+    t2[2] = T16::make_tw2(make_float2(__uint_as_float(q.x), __uint_as_float(q.y)));
+    t2[3] = T16::make_tw2(make_float2(__uint_as_float(q.z), __uint_as_float(q.w)));
   }
 
   auto twiddle = [](float re, float im, c32 t) {
@@ -431,9 +459,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     const int pos = (i + 4 * rot) & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const c32 y = twiddle(cr[r], ci[r], t2[r]);
       const int row = (4 * g + r) * 16 + 4 * w + t;
-      img_b[row * 16 + pos] = T16::pack(y.x, y.y);
+      img_b[row * 16 + pos] = T16::template twiddle_pack<FWD>(cr[r], ci[r], t2[r]);
     }
   }
   __syncthreads();
@@ -527,7 +554,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
   // ---- constants of the 4096-point passes
   T16 mat;
   mat.init(tabs, FWD, tid & 63);
-  c32 start[4], step[4], t2[4];
+  c32 start[4], step[4];
+  typename T16::tw2_t t2[4];
   {
     const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE / 2);
     const float4 s0 = ctab[tid], s1 = ctab[256 + tid], q0 = ctab[512 + g], q1 = ctab[516 + g];
@@ -537,10 +565,10 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
     step[2] = make_float2(q1.x, q1.y); step[3] = make_float2(q1.z, q1.w);
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER) + (tid & 63);
     const u32x4_t p = ftab[128], q = ftab[192];
-    t2[0] = make_float2(__uint_as_float(p.x), __uint_as_float(p.y));
-    t2[1] = make_float2(__uint_as_float(p.z), __uint_as_float(p.w));
-    t2[2] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
-    t2[3] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
+    t2[0] = T16::make_tw2(make_float2(__uint_as_float(p.x), __uint_as_float(p.y)));
+    t2[1] = T16::make_tw2(make_float2(__uint_as_float(p.z), __uint_as_float(p.w)));
+    t2[2] = T16::make_tw2(make_float2(__uint_as_float(q.x), __uint_as_float(q.y)));
+    t2[3] = T16::make_tw2(make_float2(__uint_as_float(q.z), __uint_as_float(q.w)));
   }
   auto twiddle = [](float re, float im, c32 t) {
     if (FWD) return make_float2(re * t.x - im * t.y, re * t.y + im * t.x);
@@ -595,10 +623,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
       const int rot = (t + 2 * w + (t >> 1)) & 3;
       const int pos = (i + 4 * rot) & 15;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const c32 y = twiddle(cr[r], ci[r], t2[r]);
-        img_b[((4 * g + r) * 16 + 4 * w + t) * 16 + pos] = T16::pack(y.x, y.y);
-      }
+      for (int r = 0; r < 4; ++r)
+        img_b[((4 * g + r) * 16 + 4 * w + t) * 16 + pos] = T16::template twiddle_pack<FWD>(cr[r], ci[r], t2[r]);
     }
     __syncthreads();
     // ---- pass 3
