@@ -176,6 +176,7 @@ struct Args {
   int grid = 0;
   int extra_lds = 0;
   long long grid_blocks = 0;
+  int xcd = -1;  // >= 0: log2 of the run of consecutive chunks per XCD (library option xcd_run_log2)
   long long skew = 0;  // bytes added to the output buffer's address (out of place only)
   bool csv = false, ndjson = false, hipfft = true;
   int inside_repeats = 0;
@@ -331,6 +332,7 @@ void run_one(const Args& a, int n) {
   tfft_set_option("grid_blocks_per_cu", a.grid);
   tfft_set_option("extra_lds", a.extra_lds);
   tfft_set_option("grid_blocks", a.grid_blocks);
+  tfft_set_option("xcd_run_log2", a.xcd);
   vec2_t<T>* dst = a.inplace ? d_perf : d_perf_out;
   const float ms = time_ms(s, 1, a.runs, [&] {
     thunderfft::check(tfft_exec_c2c(thunderfft::dtype_code<T>(), n, 1, d_perf, dst, batch, s), "bench");
@@ -339,6 +341,7 @@ void run_one(const Args& a, int n) {
   tfft_set_option("extra_lds", 0);
   tfft_set_option("grid_blocks", 0);
   tfft_set_option("grid_blocks_per_cu", 0);
+  tfft_set_option("xcd_run_log2", -1);
 
   double compute_ms = NAN;
   if constexpr (std::is_same_v<T, float>) {
@@ -402,6 +405,7 @@ int main(int argc, char** argv) {
     else if (k == "--grid") a.grid = std::stoi(val());
     else if (k == "--extra-lds") a.extra_lds = std::stoi(val());
     else if (k == "--grid-blocks") a.grid_blocks = std::stoll(val());
+    else if (k == "--xcd") a.xcd = std::stoi(val());
     else if (k == "--skew") a.skew = std::stoll(val());
     else if (k == "--csv") a.csv = true;
     else if (k == "--ndjson") a.ndjson = true;

@@ -223,10 +223,23 @@ __device__ __forceinline__ c32 fresh(c32 w) {
   return w;
 }
 
+// Which chunk the v-th workgroup-sized unit of work is. The dispatcher deals workgroups to the eight
+// XCDs round-robin (workgroup b runs on XCD b mod 8), so with the identity map every XCD -- its L2 and
+// its address-translation cache -- touches every eighth chunk of the whole range. Handing each XCD
+// runs of 2^lb consecutive chunks instead keeps its stream contiguous (256 KiB ... 2 MiB per run
+// measured best: +2 ... +6 points of HBM bandwidth depending on the length). A bijection on
+// [0, total): whole groups of 8 * 2^lb chunks are permuted, the remainder keeps its order.
+__device__ __forceinline__ long long xcd_chunk(long long v, long long total, int lb) {
+  const long long span = 8ll << lb;
+  if (lb <= 0 || v >= (total & ~(span - 1))) return v;
+  const long long slot = v >> 3, xcd = v & 7;
+  return ((slot >> lb) << (lb + 3)) + (xcd << lb) + (slot & ((1ll << lb) - 1));
+}
+
 template <class P, class IO, bool FWD, int MODE>
 __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename IO::raw* in, typename IO::raw* out,
                                                                  const float2* __restrict__ tw, long long batch,
-                                                                 long long nchunks) {
+                                                                 long long nchunks, int xcd_log2) {
   using raw = typename IO::raw;
   constexpr int N = P::N, E = P::E, R1 = P::R1, R2 = P::R2, R3 = P::R3, RL = P::RL, WG = P::WG;
   constexpr int C1 = P::C1, C2 = P::C2, CL = P::CL, NB1 = P::NB1, NB2 = P::NB2, NBL = P::NBL;
@@ -268,7 +281,9 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
   // lifetime starts with this HBM round trip, and everything below (store offsets, twiddle
   // bases, LDS slots) is computed while it is in flight.
   const long long chunk_raw = (long long)P::TOTAL / 2;  // raw elements per chunk
-  auto issue_loads = [&](long long chunk, raw (&dst)[NRAW]) {
+  // (the lambdas take the position in the launch order; xcd_chunk turns it into the chunk)
+  auto issue_loads = [&](long long unit, raw (&dst)[NRAW]) {
+    const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
     const raw* src = in + chunk * chunk_raw;
     const long long tr0 = chunk * TPB;
 #pragma unroll
@@ -417,7 +432,8 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
     }
   };
 
-  auto process = [&](long long chunk, bool more_after) __attribute__((always_inline)) {
+  auto process = [&](long long unit, bool more_after) __attribute__((always_inline)) {
+    const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
     c32 v[E];
     // ---- unpack the rows into butterfly order
     if constexpr (NB1 == 1) {
@@ -441,7 +457,7 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
 
     if constexpr (P::PREFETCH) {
       // the next chunk's loads go out now and land while this chunk is computed
-      const long long next = chunk + gridDim.x;
+      const long long next = unit + gridDim.x;
       if (next < nchunks) issue_loads(next, pre);
     }
 

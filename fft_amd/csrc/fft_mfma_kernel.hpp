@@ -325,7 +325,8 @@ constexpr int mfma_out_words() {
 template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false>
 __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* __restrict__ in,
                                                                      u32x4_t* __restrict__ out,
-                                                                     const float2* __restrict__ tw, long long batch) {
+                                                                     const float2* __restrict__ tw, long long batch,
+                                                                     int xcd_log2) {
   static_assert(R1 == 1 || R1 == 2 || R1 == 4 || R1 == 8 || R1 == 16, "N = 256 R1");
   static_assert(!INCR || R1 > 1, "N = 256 has no first pass");
   constexpr int OUT_WORDS = mfma_out_words<R1>();
@@ -347,13 +348,15 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   // stored, and the matrix of pass 1 has zeros between different transforms.
   u32x4_t rows[4];
   auto last_row = [&](long long t) { return R1 == 16 ? 15 : (int)min(15LL, rows_total - 16 * t - 1); };
-  auto request_rows = [&](long long t) {
+  auto request_rows = [&](long long t) {  // t: tile index
     const u32x4_t* src = in + t * 1024 + 16 * w + i;
     const int last = last_row(t);
 #pragma unroll
     for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + min(4 * G + g, last) * 64);
   };
-  request_rows(tr);
+  // tr is the position in the launch order, tile the 4096 points it stands for (xcd_chunk, fft_lds_kernel.hpp)
+  long long tile = xcd_chunk(tr, tiles, xcd_log2);
+  request_rows(tile);
 
   // ---- pass-1 twiddles in lane order, the DFT-16 matrix fragments, the pass-2 twiddles
   const float4* tw1 = reinterpret_cast<const float4*>(tabs) + tid;
@@ -407,7 +410,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     packed[j] = u32x4_t{a0, a1, a2, a3};  // rows 4g .. 4g+3 of column 64w + 4i + j
   }
   const long long next = tr + gridDim.x;
-  if (PERSIST && next < tiles) request_rows(next);
+  const long long next_tile = xcd_chunk(next, tiles, xcd_log2);
+  if (PERSIST && next < tiles) request_rows(next_tile);
   c32 run[4];
   if constexpr (INCR) {
 #pragma unroll
@@ -499,8 +503,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   __syncthreads();
 
   // ---- natural order out, 16 bytes per lane
-  const int last_cur = last_row(tr);
-  u32x4_t* dst = out + tr * 1024 + tid;
+  const int last_cur = last_row(tile);
+  u32x4_t* dst = out + tile * 1024 + tid;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[mfma_out_slot<R1>(4 * (tid + 256 * q))]);
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   if (!PERSIST || next >= tiles) break;
   __syncthreads();  // the output image is read before the next tile's pass 1 overwrites it
   tr = next;
+  tile = next_tile;
   }
 }
 
@@ -526,7 +531,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 // tables of N = 4096.
 template <class T16, bool FWD, int R0, int MINW>
 __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* __restrict__ in, u32x4_t* __restrict__ out,
-                                                                     const float2* __restrict__ tw, long long batch) {
+                                                                     const float2* __restrict__ tw, long long batch,
+                                                                     int xcd_log2) {
   static_assert(R0 == 2 || R0 == 4, "N = 8192 or 16384");
   constexpr int N = 4096 * R0;
   constexpr int OUT_WORDS = mfma_out_words<16>();
@@ -536,8 +542,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
 
   const int tid = threadIdx.x;
   const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
-  const long long tr = blockIdx.x;
-  if (tr >= batch) return;
+  if (blockIdx.x >= batch) return;
+  const long long tr = xcd_chunk(blockIdx.x, batch, xcd_log2);
   const float2* const tabs = tw + N;
 
   // ---- all rows first: lane (g, i) of wave w, row rho = 4G + g, columns c = 64w + 16j + i: points R0 (256 rho + c) + r0

@@ -37,6 +37,7 @@ struct TileArgs {
   long long in_bi, in_a, in_b, in_stride;      // element units
   long long out_bi, out_a, out_b, out_stride;
   long long q_a, q_b;  // column index of transform 0 of the tile: a*q_a + b*q_b
+  int xcd_log2;        // runs of 2^xcd_log2 consecutive tiles per XCD (xcd_chunk, fft_lds_kernel.hpp)
 };
 
 enum : int { kTileInCol = 1, kTileOutCol = 2, kTileTwiddle = 4 };
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_tile_kernel(const TileArgs
   const int hi = (tid >> 5) & 1;
 
   // ---- tile coordinates
-  const long long tile = blockIdx.x;
-  if (tile >= a.ntiles) return;
+  if (blockIdx.x >= a.ntiles) return;
+  const long long tile = xcd_chunk(blockIdx.x, a.ntiles, a.xcd_log2);
   const long long bi = tile / ((long long)a.na * a.nb);
   const int rem = (int)(tile - bi * ((long long)a.na * a.nb));
   const int ta = rem / a.nb, tb = rem - ta * a.nb;

@@ -87,21 +87,28 @@ using Plan4096Resident = Plan<4096, 16, 16, 16, 16, 256, 4, 1, 5, 1, 1, kFlagPre
 struct KernelEntry {
   const void* fn;  // __global__ function address (for the occupancy query)
   void (*launch)(const void* in, void* out, const float2* tw, long long batch, long long nchunks,
-                 unsigned grid, unsigned extra_lds, hipStream_t stream);
+                 unsigned grid, unsigned extra_lds, int xcd_log2, hipStream_t stream);
   int n, threads, tpb, e, radix[3], lds_bytes;
   int resident_per_cu = 0;  // > 0: a resident grid of this many workgroups per CU is the kernel's default launch
+  int xcd_log2 = 0;         // log2 of the run of consecutive chunks one XCD takes (xcd_chunk in fft_lds_kernel.hpp)
 };
+
+// Measured best run of consecutive chunks per XCD (interleaved A/B at 2^28 points, in place and out of place).
+constexpr int default_xcd_log2(int n, int bytes_per_point) {
+  if (bytes_per_point != 8) return 4;
+  return n <= 128 || n == 512 || n == 2048 ? 6 : n == 16384 ? 5 : 4;
+}
 
 template <class P, class IO, bool FWD, int MODE>
 void launch_plan(const void* in, void* out, const float2* tw, long long batch, long long nchunks,
-                 unsigned grid, unsigned extra_lds, hipStream_t stream) {
+                 unsigned grid, unsigned extra_lds, int xcd_log2, hipStream_t stream) {
   using raw = typename IO::raw;
   // extra_lds: unused dynamic LDS that only lowers the number of co-resident workgroups per CU
   if (extra_lds)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_lds_kernel<P, IO, FWD, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)extra_lds);
   fft_lds_kernel<P, IO, FWD, MODE><<<dim3(grid), dim3(P::WG), extra_lds, stream>>>(
-      static_cast<const raw*>(in), static_cast<raw*>(out), tw, batch, nchunks);
+      static_cast<const raw*>(in), static_cast<raw*>(out), tw, batch, nchunks, xcd_log2);
 }
 
 template <class P, class IO, bool FWD, int MODE>
@@ -117,18 +124,19 @@ KernelEntry make_entry() {
   e.radix[1] = P::R2;
   e.radix[2] = P::R3;
   e.lds_bytes = P::LDS_BYTES;
+  e.xcd_log2 = default_xcd_log2(P::N, IO::kBytesPerPoint);
   return e;
 }
 
 // Matrix-core kernel of fft_mfma_kernel.hpp as a table entry: N = 256 R1, 16 / R1 transforms per workgroup.
 template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST, int R1, bool INCR>
 void launch_mfma4096(const void* in, void* out, const float2* tw, long long batch, long long nchunks, unsigned grid,
-                     unsigned extra_lds, hipStream_t stream) {
+                     unsigned extra_lds, int xcd_log2, hipStream_t stream) {
   (void)extra_lds;
   // one-shot: one workgroup per tile of 4096 points; resident: the caller's grid (workgroups per CU x CUs)
   const unsigned blocks = PERSIST ? grid : (unsigned)nchunks;
   fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR><<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(
-      static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch);
+      static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch, xcd_log2);
 }
 
 template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false>
@@ -146,6 +154,7 @@ KernelEntry make_mfma_entry() {
   e.lds_bytes = 4 * (mfma_out_words<R1>() + (DOUBLE ? Mfma4096::IMG : 0));
   // three workgroups per CU measured best for the resident form (two: 66 %, three: 72-75 %, four: 67 %)
   e.resident_per_cu = PERSIST ? 3 : 0;
+  e.xcd_log2 = 4;
   return e;
 }
 
@@ -167,12 +176,12 @@ bool mfma_entry_for(bool forward, int mode, KernelEntry* out) {
 // N = 4096 R0 (8192, 16384), 16-bit storage: fft_mfma_big_kernel, one workgroup per transform.
 template <class T16, bool FWD, int R0, int MINW>
 void launch_mfma_big(const void* in, void* out, const float2* tw, long long batch, long long nchunks, unsigned grid,
-                     unsigned extra_lds, hipStream_t stream) {
+                     unsigned extra_lds, int xcd_log2, hipStream_t stream) {
   (void)nchunks;
   (void)grid;
   (void)extra_lds;
   fft_mfma_big_kernel<T16, FWD, R0, MINW><<<dim3((unsigned)batch), dim3(Mfma4096::WG), 0, stream>>>(
-      static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch);
+      static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch, xcd_log2);
 }
 
 template <class T16, bool FWD, int R0, int MINW>
@@ -188,6 +197,7 @@ KernelEntry make_mfma_big_entry() {
   e.radix[1] = 4096;
   e.radix[2] = 1;
   e.lds_bytes = 4 * 2 * mfma_out_words<16>();
+  e.xcd_log2 = 4;
   return e;
 }
 

@@ -69,6 +69,7 @@ struct Options {
   long long sync = 0;
   long long extra_lds = 0;
   long long grid_blocks = 0;  // absolute resident grid size; overrides grid_blocks_per_cu
+  long long xcd_run_log2 = -1;  // >= 0: runs of 2^value consecutive chunks per XCD instead of the kernel's default
 };
 
 std::mutex g_mu;
@@ -342,6 +343,7 @@ int tfft_set_option(const char* key, long long value) {
   else if (!strcmp(key, "mode")) g_opt.mode = value;
   else if (!strcmp(key, "sync")) g_opt.sync = value;
   else if (!strcmp(key, "extra_lds")) g_opt.extra_lds = value;
+  else if (!strcmp(key, "xcd_run_log2")) g_opt.xcd_run_log2 = value > 20 ? 20 : value;
   else if (!strcmp(key, "grid_blocks")) g_opt.grid_blocks = value;
   else if (!strcmp(key, "conv_resident_per_cu")) tfft::set_conv_mfma_resident_per_cu((int)value);
   else return fail(TFFT_ERR_INVALID, "tfft_set_option: unknown key '%s'", key);
@@ -361,6 +363,7 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
     p = it->second;
   }
   const bool fwd = forward != 0;
+  const long long xcd_opt = options_snapshot().xcd_run_log2;
   constexpr int kSweep = tfft::kTileInCol | tfft::kTileOutCol | tfft::kTileTwiddle;
   for (long long b = 0; b < batch; b += p.work_batch) {
     const long long group = std::min<long long>(p.work_batch, batch - b);  // transforms per launch
@@ -374,6 +377,7 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
       if (!tfft::lookup_tile(p.f[i], fwd, last ? tfft::kTileOutCol : kSweep, &t))
         return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c: no tile kernel of length %d", p.f[i]);
       tfft::TileArgs a{};
+      a.xcd_log2 = xcd_opt >= 0 ? (int)xcd_opt : 4;  // measured: +1 ... 1.5 points on the sweeps
       a.in = (i == 0) ? src : p.work;
       a.out = last ? dst : p.work;
       a.tw = p.tw_f[i];
@@ -461,7 +465,8 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
   if (grid > nchunks) grid = nchunks;
   if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, (unsigned)opt.extra_lds, s);
+  e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, (unsigned)opt.extra_lds,
+           opt.xcd_run_log2 >= 0 ? (int)opt.xcd_run_log2 : e.xcd_log2, s);
   TFFT_HIP(hipGetLastError());
   if (opt.sync) TFFT_HIP(hipStreamSynchronize(s));
   return TFFT_OK;
