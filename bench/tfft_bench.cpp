@@ -50,8 +50,9 @@ inline float hash_uniform(unsigned long long counter, unsigned long long seed) {
 // (one 16-byte load and store per thread, 4 KiB per workgroup), the fastest streaming copy found
 // on MI355X. Boxes differ by several percent, so every table carries its own copy row.
 typedef float copy_f32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void reference_copy(const copy_f32x4* in, copy_f32x4* out) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void reference_copy(const copy_f32x4* in, copy_f32x4* out, int xcd_log2) {
+  // same XCD-aware order as the library's kernels (runs of 2^xcd_log2 consecutive 4 KiB blocks per XCD)
+  const size_t i = (size_t)tfft::xcd_chunk(blockIdx.x, gridDim.x, xcd_log2) * 256 + threadIdx.x;
   __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
@@ -176,6 +177,7 @@ struct Args {
   int grid = 0;
   int extra_lds = 0;
   long long grid_blocks = 0;
+  int copy_xcd = 0;  // log2 of the run of consecutive 4 KiB blocks per XCD in the reference copy
   int xcd = -1;  // >= 0: log2 of the run of consecutive chunks per XCD (library option xcd_run_log2)
   long long skew = 0;  // bytes added to the output buffer's address (out of place only)
   bool csv = false, ndjson = false, hipfft = true;
@@ -267,6 +269,7 @@ void run_one(const Args& a, int n) {
   if (!a.inplace) {
     CHECK_HIP(hipMalloc(&d_perf_out_alloc, sizeof(vec2_t<T>) * total + (size_t)a.skew));
     d_perf_out = reinterpret_cast<vec2_t<T>*>(reinterpret_cast<char*>(d_perf_out_alloc) + a.skew);
+    if (getenv("TFFT_BENCH_ADDR")) fprintf(stderr, "n=%d in=%p out=%p\n", n, (void*)d_perf, (void*)d_perf_out);
   }
   CHECK_HIP(hipMemcpy(d_val, hs.data(), sizeof(vec2_t<T>) * vtotal, hipMemcpyHostToDevice));
   // timing buffer: the validation pattern repeated (values do not matter for timing, but keep them finite)
@@ -372,7 +375,7 @@ void run_one(const Args& a, int n) {
     const size_t bytes = sizeof(vec2_t<T>) * total;
     copy_f32x4* cdst = reinterpret_cast<copy_f32x4*>(a.inplace ? d_perf : d_perf_out);
     const float cms = time_ms(s, 1, a.runs, [&] {
-      reference_copy<<<(unsigned)(bytes / 4096), 256, 0, s>>>(reinterpret_cast<const copy_f32x4*>(d_perf), cdst);
+      reference_copy<<<(unsigned)(bytes / 4096), 256, 0, s>>>(reinterpret_cast<const copy_f32x4*>(d_perf), cdst, a.copy_xcd);
     });
     push_row("copy16B(reference)", n, "-", batch, 0.0, cms, bpp);
   }
@@ -406,6 +409,7 @@ int main(int argc, char** argv) {
     else if (k == "--extra-lds") a.extra_lds = std::stoi(val());
     else if (k == "--grid-blocks") a.grid_blocks = std::stoll(val());
     else if (k == "--xcd") a.xcd = std::stoi(val());
+    else if (k == "--copy-xcd") a.copy_xcd = std::stoi(val());
     else if (k == "--skew") a.skew = std::stoll(val());
     else if (k == "--csv") a.csv = true;
     else if (k == "--ndjson") a.ndjson = true;

@@ -74,7 +74,7 @@ using Plan256 = Plan256Mid;       using Plan256Alt = Plan256Small;
 using Plan512 = Plan512E32;       using Plan512Alt = Plan512Small;
 using Plan1024 = Plan1024E32;     using Plan1024Alt = Plan1024Small;
 using Plan2048 = Plan2048Small;   using Plan2048Alt = Plan2048Split;
-using Plan4096 = Plan4096Split;   using Plan4096Alt = Plan4096Full;
+using Plan4096 = Plan4096Full;    using Plan4096Alt = Plan4096Split;
 using Plan8192 = Plan8192Full;    using Plan8192Alt = Plan8192Split;
 using Plan16384 = Plan16384Split; using Plan16384Alt = Plan16384Full;
 
@@ -91,12 +91,18 @@ struct KernelEntry {
   int n, threads, tpb, e, radix[3], lds_bytes;
   int resident_per_cu = 0;  // > 0: a resident grid of this many workgroups per CU is the kernel's default launch
   int xcd_log2 = 0;         // log2 of the run of consecutive chunks one XCD takes (xcd_chunk in fft_lds_kernel.hpp)
+  int xcd_log2_in_place = -1;  // the same for in-place calls (-1: as xcd_log2)
 };
 
-// Measured best run of consecutive chunks per XCD (interleaved A/B at 2^28 points, in place and out of place).
-constexpr int default_xcd_log2(int n, int bytes_per_point) {
+// Measured best run of consecutive chunks per XCD (interleaved A/B at 2^28 points). Out of place the rate also
+// depends on where the two buffers lie physically: for 16 KiB chunks, runs of 16 give 81 % or 69-75 % from one
+// allocation to the next, runs of 64 give 78 % either way, so in-place calls take the short runs and
+// out-of-place calls the long ones.
+constexpr int default_xcd_log2(int n, int bytes_per_point, bool in_place) {
   if (bytes_per_point != 8) return 4;
-  return n <= 128 || n == 512 || n == 2048 ? 6 : n == 16384 ? 5 : 4;
+  if (n <= 128) return 7;
+  if (n <= 2048) return in_place ? 4 : 6;
+  return n == 4096 || n == 16384 ? 5 : 4;
 }
 
 template <class P, class IO, bool FWD, int MODE>
@@ -124,7 +130,8 @@ KernelEntry make_entry() {
   e.radix[1] = P::R2;
   e.radix[2] = P::R3;
   e.lds_bytes = P::LDS_BYTES;
-  e.xcd_log2 = default_xcd_log2(P::N, IO::kBytesPerPoint);
+  e.xcd_log2 = default_xcd_log2(P::N, IO::kBytesPerPoint, false);
+  e.xcd_log2_in_place = default_xcd_log2(P::N, IO::kBytesPerPoint, true);
   return e;
 }
 

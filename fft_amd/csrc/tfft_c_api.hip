@@ -466,7 +466,8 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
   if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, (unsigned)opt.extra_lds,
-           opt.xcd_run_log2 >= 0 ? (int)opt.xcd_run_log2 : e.xcd_log2, s);
+           opt.xcd_run_log2 >= 0 ? (int)opt.xcd_run_log2
+                                 : (d_in == d_out && e.xcd_log2_in_place >= 0 ? e.xcd_log2_in_place : e.xcd_log2), s);
   TFFT_HIP(hipGetLastError());
   if (opt.sync) TFFT_HIP(hipStreamSynchronize(s));
   return TFFT_OK;
