@@ -76,6 +76,8 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *   "conv_resident_per_cu": workgroups per CU of the fp16 convolution's resident grid (default 0 = one
  *                          workgroup per signal, which measured faster)
  *   "extra_lds"          : bytes of unused dynamic LDS per workgroup, to lower occupancy
+ *   "xcd_run_log2"       : -1 = the kernel's default; L >= 0 = every XCD takes runs of 2^L consecutive chunks of the
+ *                          batch (0 = chunk order equals launch order); results do not depend on it
  *   "grid_blocks_per_cu" also sizes the grid of kernels that are resident by default (16-bit storage,
  *                          n = 512, 1024, 2048: three workgroups per CU).
  *   "mode"               : 0 = default kernel; 1 = load/store only, 2 = no LDS exchange (both give wrong
