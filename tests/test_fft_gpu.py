@@ -391,6 +391,29 @@ def test_hip_graph_capture(kind, n):
         assert torch.equal(out, eager)
 
 
+@pytest.mark.parametrize("kind,n", [("fp32", 64), ("fp32", 1024), ("fp32", 4096), ("fp16", 256), ("fp16", 2048),
+                                    ("bf16", 4096), ("fp16", 16384), ("fp32", 1 << 16)])
+def test_xcd_chunk_order_does_not_change_results(kind, n):
+    """The order in which workgroups take chunks (runs of 2^L consecutive chunks per XCD) is a permutation of the
+    batch: every L gives bit-identical output, for batches that do not fill the last group of runs, for one-shot
+    and resident grids."""
+    per_chunk = max(1, 4096 // n)
+    batch = (1 if n > 16384 else 777) * per_chunk + per_chunk // 2 + 1
+    scale = 1.0 / np.sqrt(n) if kind == "fp16" else 1.0
+    x = (synth.uniform_complex(batch, n, seed=3) * scale).astype(np.complex64)
+    try:
+        fft_amd.set_option("xcd_run_log2", 0)
+        want, _ = run(x, kind, True)
+        for log2, grid in ((1, 0), (3, 0), (5, 0), (7, 0), (12, 0), (4, 1)):
+            fft_amd.set_option("xcd_run_log2", log2)
+            fft_amd.set_option("grid_blocks_per_cu", grid)
+            got, _ = run(x, kind, True)
+            assert np.array_equal(got, want), (kind, n, log2, grid)
+    finally:
+        fft_amd.set_option("xcd_run_log2", -1)
+        fft_amd.set_option("grid_blocks_per_cu", 0)
+
+
 def test_linearity():
     n, batch = 2048, 33
     a = synth.uniform_complex(batch, n, seed=1)
