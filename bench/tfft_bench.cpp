@@ -20,6 +20,9 @@
 // Usage: tfft_bench [--n 256,4096] [--points 268435456] [--runs 10] [--input sine|hash]
 //                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--extra-lds BYTES] [--csv] [--ndjson]
 //                   [--no-hipfft] [--inside-repeats R]   (R = 0 skips compute_ms)
+//                   [--xcd L] [--copy-xcd L]  runs of 2^L consecutive chunks per XCD in the library's kernels
+//                   (default: the kernels' own choice) and in the reference copy (default 0);
+//                   TFFT_BENCH_ADDR=1 prints the addresses of the timed buffers
 #include <hipfft/hipfft.h>
 
 #include <cmath>
