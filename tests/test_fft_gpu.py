@@ -128,6 +128,36 @@ def test_kat_bench_sine():
         assert np.max(np.abs(got - want)) < 2e-5
 
 
+@pytest.mark.parametrize("kind", ("fp16", "bf16"))
+@pytest.mark.parametrize("n", (128, 256, 1024, 4096, 8192, 16384))
+def test_kat_half_storage(kind, n):
+    """Known answers for the 16-bit kernels (matrix-core kernels from N = 256): the reference's half-precision
+    bench input sin(2 pi n / N) / sqrt(N) (sample/bench/main.cu:35-41) has two non-zero bins, -+ i sqrt(N) / 2; a
+    unit impulse at point p gives exp(-2 pi i k p / N); a constant gives the DC bin alone. Every transform of a
+    batch that leaves a partial workgroup tile is checked on its own."""
+    batch = 2 * max(1, 4096 // n) + 1
+    eps = 2.0 ** -10 if kind == "fp16" else 2.0 ** -7
+    got, _ = run(synth.bench_sine(batch, n), kind, True)
+    want = np.zeros((batch, n), dtype=np.complex128)
+    want[:, 1] = -0.5j * np.sqrt(n)
+    want[:, n - 1] = 0.5j * np.sqrt(n)
+    assert np.max(np.abs(got - want)) <= 4 * eps * np.sqrt(n), (kind, n, np.max(np.abs(got - want)))
+    x = np.zeros((batch, n), dtype=np.complex64)
+    pos = [(37 * b + 5) % n for b in range(batch)]
+    for b in range(batch):
+        x[b, pos[b]] = 1.0
+    got, _ = run(x, kind, True)
+    k = np.arange(n)
+    for b in range(batch):
+        want_b = np.exp(-2j * np.pi * k * pos[b] / n)
+        assert np.max(np.abs(got[b] - want_b)) <= 4 * eps, (kind, n, b)
+    x = np.full((batch, n), 0.25 / n, dtype=np.complex64)  # exactly representable; DC bin = 0.25
+    got, _ = run(x, kind, True)
+    want = np.zeros((batch, n), dtype=np.complex128)
+    want[:, 0] = 0.25
+    assert np.max(np.abs(got - want)) <= 2 * eps * 0.25, (kind, n)
+
+
 def test_kat_fft1d_tones():
     # reference fft1d sample: N=64, tones at bins 1+b and 7 (sample/fft1d/main.cu:16-30)
     n, batch = 64, 40
