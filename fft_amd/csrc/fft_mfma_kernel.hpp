@@ -1,4 +1,5 @@
-// 16-bit storage, N = 256 ... 4096: the passes of the transform on the matrix cores.
+// 16-bit storage, N = 256 ... 16384: the passes of the transform on the matrix cores
+// (fft_mfma4096_kernel: N = 256 ... 4096; fft_mfma_big_kernel at the end of the file: N = 8192, 16384).
 //
 // The reference computes its transforms as tensor-core products of small DFT matrices with
 // fragments of the data (thunderfft/include/thunderfft/detail/kernel/unit_kernel_fp16.cuh:97-238,
@@ -22,8 +23,8 @@
 //     rotated by a function of the row chosen by tools/lds_mfma_layout.py so that every read is
 //     conflict-free and every write at most 2-way (free for ds_write_b32);
 //   * the output goes through a natural-order image so that global stores are 16 bytes per lane.
-// Data is rounded to fp16 between passes (the storage type's own precision); twiddles and
-// accumulation are fp32. Intermediate values must fit fp16, i.e. N * max|x| < 65504 -- the bound
+// Data is rounded to fp16 between passes (the storage type's own precision); accumulation and the
+// pass-1 twiddles are fp32, the pass-2 twiddles of fp16 storage are applied on packed fp16. Intermediate values must fit fp16, i.e. N * max|x| < 65504 -- the bound
 // that also keeps the fp16 result finite.
 //
 // N = 256 R1 with R1 = 1, 2, 4, 8: a workgroup takes 16 / R1 whole transforms (the same 4096 points,
