@@ -37,7 +37,7 @@ BYTES_PER_POINT = 16  # fp32 complex read once + written once
 
 
 def cpu_baseline(n, seconds_budget=12.0):
-    """CPU FFT of the same shape on a bounded sample, best of 3 (BASELINE.md protocol)."""
+    """CPU FFT of the same shape on a bounded sample, best of 3."""
     import numpy as np
     import scipy.fft
 
