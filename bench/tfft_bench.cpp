@@ -20,7 +20,7 @@
 // Usage: tfft_bench [--n 256,4096] [--points 268435456] [--runs 10] [--input sine|hash]
 //                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--extra-lds BYTES] [--csv] [--ndjson]
 //                   [--no-hipfft] [--inside-repeats R]   (R = 0 skips compute_ms)
-//                   [--xcd L] [--copy-xcd L]  runs of 2^L consecutive chunks per XCD in the library's kernels
+//                   [--xcd L] [--copy-xcd L] [--copy-k K]  runs of 2^L consecutive chunks per XCD in the library's kernels
 //                   (default: the kernels' own choice) and in the reference copy (default 0);
 //                   TFFT_BENCH_ADDR=1 prints the addresses of the timed buffers
 #include <hipfft/hipfft.h>
@@ -160,6 +160,18 @@ bool launch_benchmark_reg_n(int n, float2* data, long long batch, unsigned repea
 #endif
 #endif
 
+// The same copy with K 16-byte loads per thread issued before its K stores: a workgroup of 4K KiB, the
+// shape of a transform kernel's life (all rows in, all rows out).
+template <int K>
+__global__ __launch_bounds__(256) void reference_copy_k(const copy_f32x4* in, copy_f32x4* out, int xcd_log2) {
+  const size_t base = (size_t)tfft::xcd_chunk(blockIdx.x, gridDim.x, xcd_log2) * (256 * K) + threadIdx.x;
+  copy_f32x4 v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = __builtin_nontemporal_load(in + base + 256 * k);
+#pragma unroll
+  for (int k = 0; k < K; ++k) __builtin_nontemporal_store(v[k], out + base + 256 * k);
+}
+
 struct Args {
 #ifdef THUNDERFFT_PROFILE_N
   std::vector<int> ns = {THUNDERFFT_PROFILE_N};
@@ -180,6 +192,7 @@ struct Args {
   int grid = 0;
   int extra_lds = 0;
   long long grid_blocks = 0;
+  int copy_k = 1;    // 16-byte loads per thread of the reference copy (1, 2, 4, 8, 16: 4 ... 64 KiB per workgroup)
   int copy_xcd = 0;  // log2 of the run of consecutive 4 KiB blocks per XCD in the reference copy
   int xcd = -1;  // >= 0: log2 of the run of consecutive chunks per XCD (library option xcd_run_log2)
   long long skew = 0;  // bytes added to the output buffer's address (out of place only)
@@ -378,7 +391,14 @@ void run_one(const Args& a, int n) {
     const size_t bytes = sizeof(vec2_t<T>) * total;
     copy_f32x4* cdst = reinterpret_cast<copy_f32x4*>(a.inplace ? d_perf : d_perf_out);
     const float cms = time_ms(s, 1, a.runs, [&] {
-      reference_copy<<<(unsigned)(bytes / 4096), 256, 0, s>>>(reinterpret_cast<const copy_f32x4*>(d_perf), cdst, a.copy_xcd);
+      const copy_f32x4* csrc = reinterpret_cast<const copy_f32x4*>(d_perf);
+      switch (a.copy_k) {
+        case 2: reference_copy_k<2><<<(unsigned)(bytes / 8192), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
+        case 4: reference_copy_k<4><<<(unsigned)(bytes / 16384), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
+        case 8: reference_copy_k<8><<<(unsigned)(bytes / 32768), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
+        case 16: reference_copy_k<16><<<(unsigned)(bytes / 65536), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
+        default: reference_copy<<<(unsigned)(bytes / 4096), 256, 0, s>>>(csrc, cdst, a.copy_xcd);
+      }
     });
     push_row("copy16B(reference)", n, "-", batch, 0.0, cms, bpp);
   }
@@ -413,6 +433,7 @@ int main(int argc, char** argv) {
     else if (k == "--grid-blocks") a.grid_blocks = std::stoll(val());
     else if (k == "--xcd") a.xcd = std::stoi(val());
     else if (k == "--copy-xcd") a.copy_xcd = std::stoi(val());
+    else if (k == "--copy-k") a.copy_k = std::stoi(val());
     else if (k == "--skew") a.skew = std::stoll(val());
     else if (k == "--csv") a.csv = true;
     else if (k == "--ndjson") a.ndjson = true;
