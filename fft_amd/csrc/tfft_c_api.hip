@@ -454,6 +454,14 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
     return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c: no kernel for %s n=%d forward=%d mode=%lld",
                 dtype_name(dtype), n, forward, opt.mode);
 
+  // Small batches of N = 512 / 1024 (fp32): the default plans hold 32 points per thread in 64-thread workgroups,
+  // which leaves most of the chip idle when there are at most two workgroups per CU; the 16-points-per-thread
+  // plans start twice as many waves and finish 10-30 % sooner there (N = 1024 x 1024: 5.0 vs 6.0 us).
+  if (opt.mode == 0 && dtype == TFFT_F32 && (n == 512 || n == 1024) &&
+      (batch + e.tpb - 1) / e.tpb <= 2LL * plan.cu_count) {
+    tfft::KernelEntry small;
+    if (lookup(dtype, n, forward != 0, 3 /* the alternative plan */, &small)) e = small;
+  }
   const long long nchunks = (batch + e.tpb - 1) / e.tpb;
   // Default: one workgroup per chunk. The hardware dispatcher then hands out chunks in address
   // order as workgroups retire, which streams HBM measurably better than a resident grid walking
