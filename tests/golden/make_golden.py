@@ -39,6 +39,40 @@ def main():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fft_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
+    conv_golden()
+
+
+def conv_golden():
+    """tests/golden/conv_golden.npz: the two convolution forms by their definitions, plain numpy sums in fp64.
+    Circular convolution of length 4096 (the reference's validation loop,
+    thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:472-483): y[b][d][n] = sum_k x[b][d][(n - k) mod N]
+    h[d][k]. Valid correlation of overlap-save tiles (sample/conv1d/main.cu:156-174): out[i] = sum_k x[i + k] t[k].
+    Inputs are values fp16 represents exactly (multiples of 2^-8 below 1), so that every storage type sees the
+    same numbers."""
+    rng = np.random.default_rng(4096)
+    n, B, D, K = 4096, 2, 3, 9
+    q = lambda shape: rng.integers(0, 256, size=shape) / 256.0
+    x = q((B, D, n)) + 1j * q((B, D, n))
+    xr = q((B, D, n))
+    h = (rng.integers(0, 16, size=(D, K)) + 1j * rng.integers(0, 16, size=(D, K))) / 16.0
+    hr = rng.integers(0, 16, size=(D, K)) / 16.0
+    idx = (np.arange(n)[:, None] - np.arange(K)[None, :]) % n  # [n, K]
+
+    def circ(sig, taps):
+        y = np.zeros(sig.shape, dtype=np.complex128)
+        for d in range(D):
+            y[:, d, :] = (sig[:, d, :][:, idx] * taps[d][None, None, :]).sum(axis=-1)
+        return y
+
+    L, KT = 1000, 9
+    xt = q(L) + 1j * q(L)
+    taps = (rng.integers(0, 16, size=KT) + 1j * rng.integers(0, 16, size=KT)) / 16.0
+    valid = np.array([np.dot(xt[i:i + KT], taps) for i in range(L - KT + 1)])
+    out = {"x": x, "h": h, "y": circ(x, h), "x_real": xr, "h_real": hr, "y_real": circ(xr + 0j, hr + 0j),
+           "tiles_x": xt, "tiles_taps": taps, "tiles_y": valid}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -201,3 +201,27 @@ def test_tiled_conv_does_not_write_past_output():
     torch.cuda.synchronize()
     assert torch.all(buf[L - K + 1:] == -7.0)
     assert torch.all(buf[: L - K + 1] != -7.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("fp16", 1e-2)])
+def test_convolution_golden_vectors(oracle_mod, dtype, tol):
+    """Committed fixtures (tests/golden/conv_golden.npz, plain numpy sums of the definitions): complex and
+    real-pair fused convolution of length 4096, and overlap-save tiles. Inputs are exact in fp16; taps go in scaled
+    by 1/64 so that fp16 intermediates stay in range, outputs are N / 64 times the definition."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conv_golden.npz"))
+    dt = TORCH_DT[dtype]
+    B, D, n = g["x"].shape
+    hp = conv.filter_spectra(interleave(g["h"] / 64.0, dt), N)
+    y = to_complex(conv.fft_conv(interleave(g["x"], dt), hp, N, conv.CONV_COMPLEX)) * (64.0 / N)
+    assert oracle_mod.rel_l2(y.reshape(B * D, n), g["y"].reshape(B * D, n)) <= tol
+    if dtype == "fp16":
+        hp = conv.filter_spectra(interleave(g["h_real"] / 64.0 + 0j, dt), N)
+        xr = torch.from_numpy(np.ascontiguousarray(g["x_real"].astype(np.float32))).to("cuda").to(dt).contiguous()
+        yr = conv.fft_conv(xr, hp, N, conv.CONV_REAL_IN_OUT).float().cpu().numpy().astype(np.float64) * (64.0 / N)
+        assert oracle_mod.rel_l2(yr.reshape(B * D, n) + 0j, g["y_real"].reshape(B * D, n)) <= tol
+    taps = g["tiles_taps"]
+    hf = conv.tiled_filter_spectrum(interleave(taps, dt), 64)
+    yt = to_complex(conv.conv1d_tiled(interleave(g["tiles_x"], dt), hf, taps.shape[0], 64))
+    assert oracle_mod.rel_l2(yt, g["tiles_y"]) <= tol

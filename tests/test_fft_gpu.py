@@ -81,6 +81,21 @@ def test_golden_vectors(oracle_mod, n):
     assert oracle_mod.rel_l2(got, g[f"inv_{n}"]) <= TOL["fp32"]
 
 
+@pytest.mark.parametrize("kind", ("fp16", "bf16"))
+@pytest.mark.parametrize("n", ALL_N)
+def test_golden_vectors_half_storage(oracle_mod, n, kind):
+    """The committed fixtures through the 16-bit kernels: inputs rounded to the storage type and scaled by
+    1/sqrt(N) (the reference's half-precision input scale, sample/bench/main.cu:36); the expected output is the
+    fixture's fp64 transform scaled alike, and the gate covers the input rounding too."""
+    g = np.load(GOLDEN)
+    scale = 1.0 / np.sqrt(n)
+    x = (g[f"x_{n}"] * scale).astype(np.complex64)
+    got, _ = run(x, kind, True)
+    assert oracle_mod.rel_l2(got, g[f"fwd_{n}"] * scale) <= TOL[kind]
+    got, _ = run(x, kind, False)
+    assert oracle_mod.rel_l2(got, g[f"inv_{n}"] * scale) <= TOL[kind]
+
+
 @pytest.mark.parametrize("n", (64, 256, 1024, 4096, 16384))
 def test_in_place_equals_out_of_place(n):
     batch = 40000 // n + 5

@@ -110,3 +110,18 @@ def test_valid_correlation_is_a_slice_of_circular_conv(oracle_mod):
     padded[0, (n - np.arange(K)) % n] = f
     circ = oracle_mod.circular_conv(x[None, :], padded)[0]
     assert np.allclose(oracle_mod.valid_correlation(x, f), circ[: n - K + 1])
+
+
+def test_convolution_golden_vectors(oracle_mod):
+    """The oracle's two convolution forms against fixtures computed from the definitions with plain numpy sums
+    (tests/golden/make_golden.py: the reference's validation loops, conv1d_fullfft_l4096_thunder.cu:472-483 and
+    sample/conv1d/main.cu:156-174)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conv_golden.npz"))
+    B, D, n = g["x"].shape
+    for x, h, y in ((g["x"], g["h"], g["y"]), (g["x_real"] + 0j, g["h_real"] + 0j, g["y_real"])):
+        want = y.reshape(B * D, n)
+        assert oracle_mod.rel_l2(oracle_mod.circular_conv(x.reshape(B * D, n), h), want) < 1e-14
+        assert oracle_mod.rel_l2(oracle_mod.circular_conv_fft(x.reshape(B * D, n), h), want) < 1e-12
+    assert oracle_mod.rel_l2(oracle_mod.valid_correlation(g["tiles_x"], g["tiles_taps"]), g["tiles_y"]) < 1e-14
