@@ -167,6 +167,27 @@ def main():
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
     wall, kernel_ms = sharding.max_over_ranks([wall, kernel_ms], dist, dev)
 
+    # The same kernel with its butterflies and LDS exchanges compiled out (library option mode = 1: the rows are
+    # loaded and stored in the transform's access pattern, results are meaningless): what this workgroup shape can
+    # stream at all. Outside the timed region; fp32 lengths that have the ablation build only.
+    shape_ms = None
+    if args.dtype == "fp32":
+        try:
+            fft_amd.set_option("mode", 1)
+            step()
+            sync()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            for a, b in ev:
+                a.record(stream)
+                step()
+                b.record(stream)
+            sync()
+            shape_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        except fft_amd.ThunderFFTError:
+            shape_ms = None
+        finally:
+            fft_amd.set_option("mode", 0)
+
     ms_per_step = wall / args.steps * 1e3
     bytes_per_launch = (BYTES_PER_POINT if args.dtype == "fp32" else BYTES_PER_POINT // 2) * n * batch
     achieved = bytes_per_launch / (kernel_ms * 1e-3) * 1e-9
@@ -208,6 +229,9 @@ def main():
                       else f"tfft::fft_lds_kernel<Plan{n}, {args.dtype} storage, forward>"),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                # fraction of peak the kernel's own load/store pattern reaches with the arithmetic compiled out
+                "load_store_only_frac": (round(bytes_per_launch / (shape_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS, 4)
+                                         if shape_ms else None),
             },
         }
         if not args.no_cpu_baseline and world == 1:
