@@ -192,7 +192,7 @@ struct Args {
   int grid = 0;
   int extra_lds = 0;
   long long grid_blocks = 0;
-  int copy_k = 1;    // 16-byte loads per thread of the reference copy (1, 2, 4, 8, 16: 4 ... 64 KiB per workgroup)
+  int copy_k = 1;    // 16-byte loads per thread of the reference copy (1, 2, 4, 8, 16, 32: 4 ... 128 KiB per workgroup)
   int copy_xcd = 0;  // log2 of the run of consecutive 4 KiB blocks per XCD in the reference copy
   int xcd = -1;  // >= 0: log2 of the run of consecutive chunks per XCD (library option xcd_run_log2)
   long long skew = 0;  // bytes added to the output buffer's address (out of place only)
@@ -397,6 +397,7 @@ void run_one(const Args& a, int n) {
         case 4: reference_copy_k<4><<<(unsigned)(bytes / 16384), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
         case 8: reference_copy_k<8><<<(unsigned)(bytes / 32768), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
         case 16: reference_copy_k<16><<<(unsigned)(bytes / 65536), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
+        case 32: reference_copy_k<32><<<(unsigned)(bytes / 131072), 256, 0, s>>>(csrc, cdst, a.copy_xcd); break;
         default: reference_copy<<<(unsigned)(bytes / 4096), 256, 0, s>>>(csrc, cdst, a.copy_xcd);
       }
     });
