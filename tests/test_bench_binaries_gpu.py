@@ -80,3 +80,32 @@ def test_tfft_bench_sinks():
         assert r["e2e_ms"] > 0 and r["compute_ms"] > 0
     out = run("tfft_bench", "--n", "1024", "--points", 1 << 20, "--runs", 2, "--csv")
     assert out.splitlines()[0] == "type,N,radix,B,max_abs_err,compute_ms,e2e_ms,gflops,gbps,hbm_frac"
+
+
+@pytest.mark.parametrize("extra", [[], ["--dtype", "fp16"]])
+def test_bench_py_prints_one_json_line_with_the_contract_keys(extra):
+    """bench.py --gpus 1 --steps K --warmup W: one JSON line on stdout with the driver's keys, the roofline object
+    (achieved / peak = frac, measured on the launch stream) and, at one GPU, the CPU baseline object. A small batch
+    keeps it short; the keys and their consistency are what is checked, not the rate."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "2048"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
