@@ -21,7 +21,7 @@
 //                   [--dtype fp32|fp16|bf16] [--inplace 0|1] [--mode 0|1|2] [--grid K] [--extra-lds BYTES] [--csv] [--ndjson]
 //                   [--no-hipfft] [--inside-repeats R]   (R = 0 skips compute_ms)
 //                   [--xcd L] [--copy-xcd L] [--copy-k K]  runs of 2^L consecutive chunks per XCD in the library's kernels
-//                   (default: the kernels' own choice) and in the reference copy (default 0);
+//                   (default: the kernels' own choice) and in the reference copy (default 8);
 //                   TFFT_BENCH_ADDR=1 prints the addresses of the timed buffers
 #include <hipfft/hipfft.h>
 
@@ -193,7 +193,7 @@ struct Args {
   int extra_lds = 0;
   long long grid_blocks = 0;
   int copy_k = 1;    // 16-byte loads per thread of the reference copy (1, 2, 4, 8, 16, 32: 4 ... 128 KiB per workgroup)
-  int copy_xcd = 0;  // log2 of the run of consecutive 4 KiB blocks per XCD in the reference copy
+  int copy_xcd = 8;  // log2 of the run of consecutive 4 KiB blocks per XCD in the reference copy (1 MiB runs measured best)
   int xcd = -1;  // >= 0: log2 of the run of consecutive chunks per XCD (library option xcd_run_log2)
   long long skew = 0;  // bytes added to the output buffer's address (out of place only)
   bool csv = false, ndjson = false, hipfft = true;
