@@ -42,15 +42,15 @@ $(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh 
 	$(HIPCC) -O3 -std=c++17 -fno-slp-vectorize --offload-arch=$(ARCH) -Iinclude -o $@ bench/tfft_bench.cpp \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
-bench/thff_conv1d%: bench/thff_conv1d%.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+bench/thff_conv1d%: bench/thff_conv1d%.cpp bench/harness.hpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
-bench/thff_fft: bench/thff_fft.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+bench/thff_fft: bench/thff_fft.cpp bench/harness.hpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
-bench/thff_conv1d: bench/thff_conv1d.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+bench/thff_conv1d: bench/thff_conv1d.cpp bench/harness.hpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 

@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched 1D C2C FFT, N=4096 fp32, 2^28 points per GPU, on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--n LENGTH]
 
 One "step" is one pass of the hot path (tfft_exec_c2c through the C ABI) over the whole batch,
 from one device-resident buffer to another, the call shape of the reference's public entry point
 (thunderfft/sample/fft1d/main.cu:116; `--in-place` selects the reference bench's in-place form,
-thunderfft/sample/bench/baseline/thunderfft_bench.h:124-131). For N > 1
-the driver starts one process per GPU (torch.distributed.run); the batch dimension shards
-trivially, every rank transforms its own 2^28 points (weak scaling) and no collective touches
-the data path. Rank 0 prints ONE JSON line:
+thunderfft/sample/bench/baseline/thunderfft_bench.h:124-131).
+
+N > 1: one process per GPU. Started under torch.distributed.run (WORLD_SIZE set) the script is one
+rank; started plainly with --gpus N > 1 it first starts torch.distributed.run with N ranks of itself
+as a CHILD process (decided from argv alone, before torch or the HIP library are imported: nothing
+that has touched a GPU is ever replaced or re-launched) and relays rank 0's line. The batch
+dimension shards trivially and no collective touches the data path:
+  --scaling weak   every rank transforms its own 2^28 points (default)
+  --scaling strong the 2^28 points (--batch transforms) are split over the ranks in contiguous shards
+`n_gpus` is the all-reduced count of ranks that took part. Rank 0 prints ONE JSON line:
 
   value        whole-job GFLOP/s with the 5 N log2 N convention, inputs resident in HBM
   roofline     algorithmic HBM bytes (16 B per point: one read + one write) per launch divided
                by the mean launch duration measured with events on the launch stream, against
                8 TB/s; `traffic` is the PMC-measured HBM bytes per launch recorded under
-               profiles/ for this same kernel (null if no such record matches)
+               profiles/ for this same kernel (null if no such record matches). Multi-pass lengths
+               (n > 16384) also report the per-sweep model: every sweep reads and writes all points.
   cpu_baseline the CPU FFT (scipy/pocketfft on complex64, all host cores of the box's share)
                timed on a bounded sample of the same workload; a reported baseline, not a target
 """
@@ -31,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_FFT = 4096
-BATCH = 65536  # 2^28 points: 2 GiB of fp32 complex per GPU
+POINTS = 1 << 28  # per launch: 2 GiB of fp32 complex (batch 65536 at N = 4096)
 HBM_PEAK_GBPS = 8000.0
 BYTES_PER_POINT = 16  # fp32 complex read once + written once
 
@@ -81,139 +88,234 @@ def recorded_traffic(kernel_tag):
     return entry.get("hbm_bytes_per_launch") if entry else None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_FFT)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--n", "--fft-len", dest="n", type=int, default=N_FFT,
+                    help="transform length (use --fft-len behind torch.distributed.run, whose own parser takes "
+                         "--n for an abbreviation)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="transforms per rank (weak) or in total (strong); default 2^28 / n")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--in-place", action="store_true", help="transform the buffer in place (the reference bench protocol) instead of x -> y")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=("fp32", "fp16", "bf16"), default="fp32",
                     help="storage type; fp32 is the headline configuration, fp16 / bf16 the 16-bit one (8 B per point)")
     ap.add_argument("--out-of-place", action="store_true", help="force x -> y for 16-bit storage (default there: in place)")
-    args = ap.parse_args()
+    ap.add_argument("--stub-step", action="store_true",
+                    help="launcher self-test without a GPU: gloo ranks, a sleep as the step; the line says data=stub")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.batch <= 0:
+        args.batch = max(1, POINTS // args.n)
     # fp32: x -> y (the call shape of the reference's fft1d sample; measured equal or faster than in place).
     # 16-bit storage: in place like the reference's bench (sample/bench/baseline/thunderfft_bench.h:124-125);
     # writing the rows just read measured 6 points faster than a separate output stream there.
     args.out_of_place = args.out_of_place or (args.dtype == "fp32" and not args.in_place)
+    return args
+
+
+def launch_ranks(args, argv):
+    """Start `--gpus` ranks of this script under torch.distributed.run as a child process, pass rank 0's JSON line
+    through, return the child's exit code. Called before anything GPU-related is imported."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--",  # everything after it is the script and its arguments (its own --n would read as an abbreviation)
+           os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        # only the result line goes to stdout; anything else a rank printed there goes to stderr
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+    return proc.wait()
+
+
+def kernel_label(dtype, n, radix):
+    if dtype == "fp32":
+        if n > 16384:
+            return (f"tfft::fft_tile_kernel x {len(radix)} sweeps ({'x'.join(map(str, radix))}), forward: "
+                    "strided column sweeps with four-step twiddles, last sweep writes natural order")
+        return f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>"
+    if 256 <= n <= 4096:
+        return f"tfft::fft_mfma4096_kernel<{dtype}, forward, N={n}>"
+    if n > 4096:
+        return f"tfft::fft_mfma_big_kernel<{dtype}, forward, N={n}>"
+    return f"tfft::fft_lds_kernel<Plan{n}, {dtype} storage, forward>"
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args, argv))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it plainly (it launches its own "
+                         f"ranks) or with --nproc-per-node {args.gpus}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
 
-    import fft_amd
     from fft_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the FFT path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    stub = args.stub_step
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the FFT path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    # ranks that really take part (not the number asked for)
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
+    if dist:
+        dist.all_reduce(ones)
+    n_ranks = int(ones.item())
 
-    n, batch = args.n, args.batch
-    # synthetic input, uniform(-1, 1), generated on the device (values do not affect timing)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.rand(batch, n, 2, device=dev, generator=g) * 2 - 1
-    if args.dtype != "fp32":
-        # 16-bit storage: inputs scaled by 1/sqrt(N) as the reference does (sample/bench/main.cu:36)
-        x = (x * float(n) ** -0.5).to(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
-    # An unnormalised forward FFT grows random data by sqrt(N) per pass. In place, start low enough
-    # (an exact power of two, mantissas untouched) that up to RESCALE_EVERY passes stay finite.
-    RESCALE_EVERY = 32
-    if not args.out_of_place:
-        x.mul_(float(n) ** (-min(args.steps + args.warmup, RESCALE_EVERY) / 4.0))
-    y = torch.empty_like(x) if args.out_of_place else x
-    fft_amd.ThunderFFTInitialize(args.dtype, n)
-    stream = torch.cuda.current_stream(dev)
+    n = args.n
+    if args.scaling == "strong":
+        total_batch = args.batch
+        _, batch = sharding.shard_range(total_batch, world, rank)
+    else:
+        batch = args.batch
+        total_batch = batch * world
 
-    def step():
-        fft_amd.ThunderFFT_global(x, y, batch, n, True, stream)
+    if stub:
+        info = {"radix": [n]}
 
-    done = 0
+        def step():
+            time.sleep(0.002)
 
-    def keep_finite():
-        # only reached on runs longer than RESCALE_EVERY passes; outside the event-timed launches
-        nonlocal done
-        done += 1
-        if not args.out_of_place and done % RESCALE_EVERY == 0:
-            x.mul_(float(n) ** (-RESCALE_EVERY / 2.0))
+        def keep_finite():
+            pass
 
-    def sync():
-        torch.cuda.synchronize(dev)
+        def sync():
+            pass
+
+        stream = None
+    else:
+        import fft_amd
+
+        # synthetic input, uniform(-1, 1), generated on the device (values do not affect timing)
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        x = torch.rand(max(batch, 1), n, 2, device=dev, generator=g) * 2 - 1
+        if args.dtype != "fp32":
+            # 16-bit storage: inputs scaled by 1/sqrt(N) as the reference does (sample/bench/main.cu:36)
+            x = (x * float(n) ** -0.5).to(torch.float16 if args.dtype == "fp16" else torch.bfloat16)
+        # An unnormalised forward FFT grows random data by sqrt(N) per pass. In place, start low enough
+        # (an exact power of two, mantissas untouched) that up to RESCALE_EVERY passes stay finite.
+        RESCALE_EVERY = 32
+        if not args.out_of_place:
+            x.mul_(float(n) ** (-min(args.steps + args.warmup, RESCALE_EVERY) / 4.0))
+        y = torch.empty_like(x) if args.out_of_place else x
+        fft_amd.ThunderFFTInitialize(args.dtype, n)
+        info = fft_amd.plan_info(args.dtype, n)
+        stream = torch.cuda.current_stream(dev)
+
+        def step():
+            fft_amd.ThunderFFT_global(x, y, batch, n, True, stream)
+
+        done = 0
+
+        def keep_finite():
+            # only reached on runs longer than RESCALE_EVERY passes; outside the event-timed launches
+            nonlocal done
+            done += 1
+            if not args.out_of_place and done % RESCALE_EVERY == 0:
+                x.mul_(float(n) ** (-RESCALE_EVERY / 2.0))
+
+        def sync():
+            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
         keep_finite()
     sharding.barrier(dist, sync)
 
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if not stub:
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        starts[i].record(stream)
+        if not stub:
+            starts[i].record(stream)
         step()
-        ends[i].record(stream)
+        if not stub:
+            ends[i].record(stream)
         keep_finite()
     sharding.barrier(dist, sync)
     wall = time.perf_counter() - t0
 
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+    kernel_ms = (wall / args.steps * 1e3 if stub
+                 else sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps)
     wall, kernel_ms = sharding.max_over_ranks([wall, kernel_ms], dist, dev)
 
-    # The same kernel with its butterflies and LDS exchanges compiled out (library option mode = 1: the rows are
-    # loaded and stored in the transform's access pattern, results are meaningless): what this workgroup shape can
-    # stream at all. Outside the timed region; fp32 lengths that have the ablation build only.
+    # The same kernel with its butterflies and LDS exchanges compiled out (tfft_bench_access_pattern, pattern 1: the
+    # rows are loaded and stored in the transform's access pattern, the output is meaningless): what this workgroup
+    # shape can stream at all. Its own entry point, outside the timed region; fp32 lengths that have the build only.
     shape_ms = None
-    if args.dtype == "fp32":
+    if not stub and args.dtype == "fp32" and n <= 16384 and batch > 0:
         try:
-            fft_amd.set_option("mode", 1)
-            step()
+            scratch = y if args.out_of_place else torch.empty_like(x)  # never the benchmark's live data in place
+            fft_amd.bench_access_pattern(x, scratch, batch, n, 1, True, stream)
             sync()
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
             for a, b in ev:
                 a.record(stream)
-                step()
+                fft_amd.bench_access_pattern(x, scratch, batch, n, 1, True, stream)
                 b.record(stream)
             sync()
             shape_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         except fft_amd.ThunderFFTError:
             shape_ms = None
-        finally:
-            fft_amd.set_option("mode", 0)
 
     ms_per_step = wall / args.steps * 1e3
-    bytes_per_launch = (BYTES_PER_POINT if args.dtype == "fp32" else BYTES_PER_POINT // 2) * n * batch
+    per_point = BYTES_PER_POINT if args.dtype == "fp32" else BYTES_PER_POINT // 2
+    # the slowest rank's launch moved that rank's shard; in both scaling modes rank 0 holds a largest shard
+    bytes_per_launch = per_point * n * batch
     achieved = bytes_per_launch / (kernel_ms * 1e-3) * 1e-9
+    sweeps = len(info["radix"]) if n > 16384 else 1
 
     if rank == 0:
-        info = fft_amd.plan_info(args.dtype, n)
         line = {
             "metric": f"batched 1D C2C FFT GFLOP/s (5NlogN) + % HBM roofline, N={n} {args.dtype}",
-            "value": round(sharding.aggregate_gflops(n, batch, world, ms_per_step * 1e-3), 1),
+            "value": round(5.0 * n * math.log2(n) * total_batch / (ms_per_step * 1e-3) * 1e-9, 1),
             "unit": "GFLOP/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             # fp32 storage: fp32 VALU arithmetic; 16-bit storage at N >= 256: 16-bit matrix-core operands, fp32 accumulation
             "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.dtype],
-            "data": "synthetic",
+            "data": "stub (no GPU work: launcher self-test)" if stub else "synthetic",
             "config": {
                 "workload": f"batched 1D C2C FFT N={n} batch={batch} per GPU {args.dtype}, "
                             f"{'out of place' if args.out_of_place else 'in place'}, forward",
                 "points_per_gpu": n * batch,
+                "total_batch": total_batch,
                 "radix": "x".join(str(r) for r in info["radix"]),
-                "parallelism": f"batch-sharded x{world}, no data-path collective",
+                "parallelism": f"batch-sharded x{n_ranks} ({args.scaling} scaling), no data-path collective",
             },
             "roofline": {
                 "bound": "hbm",
@@ -223,10 +325,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": recorded_traffic(f"fft_lds_kernel_f32_n{n}_b{batch}") if args.dtype == "fp32"
                 else recorded_traffic(f"fft_kernel_{args.dtype}_n{n}_b{batch}"),
-                "kernel": f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>" if args.dtype == "fp32"
-                else (f"tfft::fft_mfma4096_kernel<{args.dtype}, forward, N={n}>" if 256 <= n <= 4096
-                      else f"tfft::fft_mfma_big_kernel<{args.dtype}, forward, N={n}>" if n > 4096
-                      else f"tfft::fft_lds_kernel<Plan{n}, {args.dtype} storage, forward>"),
+                "kernel": kernel_label(args.dtype, n, info["radix"]),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 # fraction of peak the kernel's own load/store pattern reaches with the arithmetic compiled out
@@ -234,11 +333,18 @@ def main():
                                          if shape_ms else None),
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if sweeps > 1:
+            # multi-pass transform: the compulsory-bytes fraction above cannot exceed 1 / sweeps; this is the
+            # fraction of peak at which the sweeps themselves stream (every sweep reads and writes every point)
+            line["roofline"]["sweeps"] = sweeps
+            line["roofline"]["sweep_model_bytes_per_launch"] = sweeps * bytes_per_launch
+            line["roofline"]["frac_sweep_model"] = round(sweeps * achieved / HBM_PEAK_GBPS, 4)
+        if not args.no_cpu_baseline and world == 1 and not stub:
             line["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(line), flush=True)
 
-    fft_amd.ThunderFFTFinalize(args.dtype)
+    if not stub:
+        fft_amd.ThunderFFTFinalize(args.dtype)
     if dist:
         dist.destroy_process_group()
 

@@ -335,7 +335,6 @@ void run_one(const Args& a, int n) {
   if (info.radix[2] > 1) radix << "x" << info.radix[2];
   if (n > 16384) radix << " sweeps";
 
-  tfft_set_option("mode", 0);
   thunderfft::check(tfft_exec_c2c(thunderfft::dtype_code<T>(), n, 1, d_val, d_val_out, vbatch, s), "validate");
   CHECK_HIP(hipStreamSynchronize(s));
   std::vector<vec2_t<T>> got(vtotal);
@@ -347,20 +346,22 @@ void run_one(const Args& a, int n) {
     err = max_abs_err(ref.data(), gf.data(), vtotal);
   }
 
-  tfft_set_option("mode", a.mode);
-  tfft_set_option("grid_blocks_per_cu", a.grid);
-  tfft_set_option("extra_lds", a.extra_lds);
-  tfft_set_option("grid_blocks", a.grid_blocks);
-  tfft_set_option("xcd_run_log2", a.xcd);
+  // --mode 1 / 2 time the measurement builds (loads and stores only / no LDS exchange: meaningless output),
+  // every other value is a plan of the transform itself
+  tfft_exec_options opt;
+  tfft_exec_options_init(&opt);
+  opt.plan = (a.mode == 1 || a.mode == 2) ? 0 : a.mode;
+  opt.grid_blocks_per_cu = a.grid;
+  opt.extra_lds = a.extra_lds;
+  opt.grid_blocks = a.grid_blocks;
+  opt.xcd_run_log2 = a.xcd;
   vec2_t<T>* dst = a.inplace ? d_perf : d_perf_out;
   const float ms = time_ms(s, 1, a.runs, [&] {
-    thunderfft::check(tfft_exec_c2c(thunderfft::dtype_code<T>(), n, 1, d_perf, dst, batch, s), "bench");
+    if (a.mode == 1 || a.mode == 2)
+      thunderfft::check(tfft_bench_access_pattern(thunderfft::dtype_code<T>(), n, 1, a.mode, d_perf, dst, batch, s, &opt), "bench");
+    else
+      thunderfft::check(tfft_exec_c2c_opt(thunderfft::dtype_code<T>(), n, 1, d_perf, dst, batch, s, &opt), "bench");
   });
-  tfft_set_option("mode", 0);
-  tfft_set_option("extra_lds", 0);
-  tfft_set_option("grid_blocks", 0);
-  tfft_set_option("grid_blocks_per_cu", 0);
-  tfft_set_option("xcd_run_log2", -1);
 
   double compute_ms = NAN;
   if constexpr (std::is_same_v<T, float>) {

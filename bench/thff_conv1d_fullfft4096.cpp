@@ -1,249 +1,224 @@
-// Fused FFT-convolution benchmark, N = 4096, fp16 storage: the MI355X build of the reference's
-// thff_conv1d_fullfft4096 (thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:304-537).
+// thff_conv1d_fullfft4096 for MI355X: times the fused circular convolution of length 4096 on fp16 storage,
+//   y[b][d] = IDFT(DFT(x[b][d]) * DFT(h[d])),
+// through the C ABI (tfft_exec_c2c, tfft_conv_filter_layout, tfft_conv_exec).
 //
-// Same 11 positional arguments in the same order (:305-327)
-//   K device B D warmup runs include_filter_fft validate filter_fft_mode real_input real_filter
-// and the same first stdout line (:452-455), which Figure5_1dFFT/benchmark_figure5_1dfft.py:27-34
-// parses; the validation block prints the reference's three lines (:516-522). Inputs come from
-// std::srand(42) / std::rand() in the reference's order (:335-361), so the data are the same.
-// filter_fft_mode 0 uses hipFFT (fp32) for the filter spectra where the reference uses cuFFT,
-// mode 1 the library's own fp16-storage transform. Everything on the device goes through the C ABI
-// (tfft_exec_c2c, tfft_conv_filter_layout, tfft_conv_exec).
-#include <hip/hip_fp16.h>
-#include <hip/hip_runtime.h>
+// Contract kept from the reference's sample of the same name, because its Figure-5 driver starts the binary
+// and parses its output (Figure5_1dFFT/benchmark_figure5_1dfft.py:27-53):
+//   * the eleven positional arguments, in this order
+//     (thunderfft/sample/conv1d/conv1d_fullfft_l4096_thunder.cu:305-327):
+//       K device B D warmup runs include_filter_fft validate filter_fft_mode real_input real_filter
+//   * the "ThunderFFT full FFT-Conv (...) time: X ms" line (:452-455) and the three "Validation vs direct
+//     circular ..." lines (:516-522).
+// Everything else is this build's own: inputs come from a counter-based generator, the expected values are
+// summed in fp64 from the definition of the circular convolution, and large runs validate a spread sample
+// of the signals instead of all of them. filter_fft_mode 0 transforms the taps in fp32 with hipFFT (the
+// reference: cuFFT), mode 1 with the library's own fp16-storage transform.
+// Environment: TFFT_MODE=3 selects the fp32-VALU kernels, TFFT_CONV_RESIDENT_PER_CU=k a resident grid.
 #include <hipfft/hipfft.h>
 
-#include <cmath>
-#include <cstdlib>
+#include <algorithm>
 #include <iomanip>
 #include <iostream>
-#include <vector>
 
-#include <thunderfft/thunderfft.cuh>
-
-using cpx_h = __half2;
+#include "harness.hpp"
 
 namespace {
 
-constexpr int kN = 4096;
+using harness::cplx;
+using harness::DeviceArray;
+constexpr int kLen = 4096;
 
-#define CHECK_HIPFFT(call)                                                                  \
-  do {                                                                                      \
-    hipfftResult r_ = (call);                                                               \
-    if (r_ != HIPFFT_SUCCESS) {                                                             \
-      std::fprintf(stderr, "hipFFT error %s:%d: %d\n", __FILE__, __LINE__, (int)r_);        \
-      std::exit(EXIT_FAILURE);                                                              \
-    }                                                                                       \
-  } while (0)
-
-__global__ void f32_to_h2(const float2* __restrict__ in, __half2* __restrict__ out, int n) {
-  const int i = int(blockIdx.x) * int(blockDim.x) + int(threadIdx.x);
-  if (i < n) out[i] = __floats2half2_rn(in[i].x, in[i].y);
-}
-
-// the reference's measure_execution_ms (sample/utils.h:33-57): mean over `runs` back-to-back calls
-template <class F>
-float measure_execution_ms(F&& fn, unsigned warmup, unsigned runs) {
-  hipEvent_t start, stop;
-  CHECK_HIP(hipEventCreate(&start));
-  CHECK_HIP(hipEventCreate(&stop));
-  CHECK_HIP(hipDeviceSynchronize());
-  for (unsigned i = 0; i < warmup; ++i) fn();
-  CHECK_HIP(hipDeviceSynchronize());
-  CHECK_HIP(hipEventRecord(start));
-  for (unsigned i = 0; i < runs; ++i) fn();
-  CHECK_HIP(hipEventRecord(stop));
-  CHECK_HIP(hipDeviceSynchronize());
-  float ms = 0.f;
-  CHECK_HIP(hipEventElapsedTime(&ms, start, stop));
-  CHECK_HIP(hipEventDestroy(start));
-  CHECK_HIP(hipEventDestroy(stop));
-  return ms / float(runs);
-}
-
-void check_tfft(int rc, const char* what) {
-  if (rc != TFFT_OK) {
-    std::fprintf(stderr, "%s: %s\n", what, tfft_last_error());
-    std::exit(EXIT_FAILURE);
+struct Config {
+  int taps = 9, device = 0, B = 1, D = 1, warmup = 5, runs = 30;
+  int filter_in_loop = 1, validate = 1, filter_fft_mode = 1, real_input = 0, real_filter = 0;
+  int conv_kind() const {
+    if (!real_input) return TFFT_CONV_COMPLEX;
+    return real_filter ? TFFT_CONV_REAL_IN_OUT : TFFT_CONV_REAL_IN;
   }
+  size_t signals() const { return (size_t)B * D; }
+};
+
+Config parse(int argc, char** argv) {
+  Config c;
+  harness::positional(argc, argv, {&c.taps, &c.device, &c.B, &c.D, &c.warmup, &c.runs, &c.filter_in_loop, &c.validate,
+                                   &c.filter_fft_mode, &c.real_input, &c.real_filter});
+  if (c.taps < 1 || c.taps > kLen) harness::die("K must be in [1, " + std::to_string(kLen) + "]");
+  if (c.B < 1 || c.D < 1 || c.runs < 1 || c.warmup < 0) harness::die("B, D and runs must be positive");
+  return c;
+}
+
+// The synthetic problem as the device sees it: fp16 signals, taps already divided by N (so that the
+// unnormalised inverse returns the convolution times N and the spectra product stays inside fp16 range).
+struct Problem {
+  std::vector<__half2> x;      // [B*D][4096], imaginary parts zero for real input
+  std::vector<float2> h_f32;   // [D][4096], zero beyond the taps
+  std::vector<__half2> h_f16;  // the same rounded to fp16
+  explicit Problem(const Config& c) : x(c.signals() * kLen), h_f32((size_t)c.D * kLen, make_float2(0.f, 0.f)),
+                                      h_f16((size_t)c.D * kLen, __floats2half2_rn(0.f, 0.f)) {
+    for (size_t i = 0; i < x.size(); ++i)
+      x[i] = __floats2half2_rn(harness::uniform01(2 * i, 1), c.real_input ? 0.f : harness::uniform01(2 * i + 1, 1));
+    for (int d = 0; d < c.D; ++d)
+      for (int k = 0; k < c.taps; ++k) {
+        const uint64_t id = 2 * ((uint64_t)d * kLen + k);
+        const float2 v = make_float2(harness::uniform01(id, 2) / kLen,
+                                     c.real_filter ? 0.f : harness::uniform01(id + 1, 2) / kLen);
+        h_f32[(size_t)d * kLen + k] = v;
+        h_f16[(size_t)d * kLen + k] = __floats2half2_rn(v.x, v.y);
+      }
+  }
+};
+
+// Filter spectra in the order the fused kernel reads, remade on every call of prepare().
+class FilterSpectra {
+ public:
+  FilterSpectra(const Config& c, const Problem& p, const tfft_exec_options& opt)
+      : D_(c.D), mode_(c.filter_fft_mode), opt_(opt), spectra_((size_t)c.D * kLen), permuted_((size_t)c.D * kLen) {
+    if (mode_ == 0) {
+      taps32_.upload(p.h_f32);
+      spectra32_.resize(p.h_f32.size());
+      if (hipfftPlan1d(&plan_, kLen, HIPFFT_C2C, D_) != HIPFFT_SUCCESS) harness::die("hipfftPlan1d failed");
+    } else {
+      taps16_.upload(p.h_f16);
+    }
+  }
+  ~FilterSpectra() {
+    if (plan_) hipfftDestroy(plan_);
+  }
+  void prepare() {
+    if (mode_ == 0) {
+      if (hipfftExecC2C(plan_, reinterpret_cast<hipfftComplex*>(taps32_.get()),
+                        reinterpret_cast<hipfftComplex*>(spectra32_.get()), HIPFFT_FORWARD) != HIPFFT_SUCCESS)
+        harness::die("hipfftExecC2C failed");
+      harness::narrow(spectra32_.get(), spectra_.get(), spectra_.size());
+    } else {
+      harness::tfft_ok(tfft_exec_c2c(TFFT_F16, kLen, 1, taps16_.get(), spectra_.get(), D_, nullptr), "filter transform");
+    }
+    harness::tfft_ok(tfft_conv_filter_layout_opt(TFFT_F16, kLen, spectra_.get(), permuted_.get(), D_, nullptr, &opt_),
+                     "filter layout");
+  }
+  const __half2* permuted() const { return permuted_.get(); }
+
+ private:
+  int D_, mode_;
+  tfft_exec_options opt_;
+  hipfftHandle plan_ = 0;
+  DeviceArray<float2> taps32_, spectra32_;
+  DeviceArray<__half2> taps16_, spectra_, permuted_;
+};
+
+// Expected results by the definitions, in fp64, for a sample of the signals:
+//   convolution  c[n] = sum_k h[k] x[(n - k) mod N],  correlation  r[n] = sum_k h[k] x[(n + k) mod N].
+// The kernel returns N * c (unnormalised inverse), so "raw" is expected to be off by that factor, "raw/N"
+// to match c, and the correlation line shows that the result is not r.
+struct Validation {
+  harness::ErrorSums raw, scaled, corr;
+  size_t checked = 0;
+};
+
+Validation validate(const Config& c, const Problem& p, const std::vector<cplx>& y_of_signal_sample,
+                    const std::vector<size_t>& sample) {
+  Validation v;
+  v.checked = sample.size();
+  const bool taps16 = c.filter_fft_mode != 0;  // the taps as the device read them
+  for (size_t s = 0; s < sample.size(); ++s) {
+    const size_t sig = sample[s];
+    const size_t d = sig % (size_t)c.D;  // signal (b, d) uses filter d
+    std::vector<cplx> x(kLen), h(c.taps);
+    for (int n = 0; n < kLen; ++n) x[n] = harness::to_cplx(p.x[sig * kLen + n]);
+    for (int k = 0; k < c.taps; ++k)
+      h[k] = taps16 ? harness::to_cplx(p.h_f16[d * kLen + k]) : harness::to_cplx(p.h_f32[d * kLen + k]);
+    for (int n = 0; n < kLen; ++n) {
+      cplx conv = 0, corr = 0;
+      for (int k = 0; k < c.taps; ++k) {
+        conv += h[k] * x[(n - k) & (kLen - 1)];
+        corr += h[k] * x[(n + k) & (kLen - 1)];
+      }
+      const cplx got = y_of_signal_sample[s * kLen + n];
+      v.raw.add(got, conv);
+      v.scaled.add(got / (double)kLen, conv);
+      v.corr.add(got / (double)kLen, corr);
+    }
+  }
+  return v;
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
-  int K = 9, device = 0, B = 1, D = 1, warmup = 5, runs = 30;
-  int include_filter_fft = 1, validate = 1, filter_fft_mode = 1, real_input = 0, real_filter = 0;
-  if (argc >= 2) K = std::atoi(argv[1]);
-  if (argc >= 3) device = std::atoi(argv[2]);
-  if (argc >= 4) B = std::atoi(argv[3]);
-  if (argc >= 5) D = std::atoi(argv[4]);
-  if (argc >= 6) warmup = std::atoi(argv[5]);
-  if (argc >= 7) runs = std::atoi(argv[6]);
-  if (argc >= 8) include_filter_fft = std::atoi(argv[7]);
-  if (argc >= 9) validate = std::atoi(argv[8]);
-  if (argc >= 10) filter_fft_mode = std::atoi(argv[9]);
-  if (argc >= 11) real_input = std::atoi(argv[10]);
-  if (argc >= 12) real_filter = std::atoi(argv[11]);
+  const Config cfg = parse(argc, argv);
+  harness::hip_ok(hipSetDevice(cfg.device), "hipSetDevice");
+  tfft_exec_options opt;
+  tfft_exec_options_init(&opt);
+  if (const char* e = std::getenv("TFFT_MODE")) opt.plan = std::atoi(e);
+  if (const char* e = std::getenv("TFFT_CONV_RESIDENT_PER_CU")) opt.grid_blocks_per_cu = std::atoi(e);
 
-  if (K < 1 || K > kN) {
-    std::cerr << "K must be in [1, " << kN << "]\n";
-    return EXIT_FAILURE;
+  const Problem problem(cfg);
+  const int kind = cfg.conv_kind();
+  const size_t points = cfg.signals() * kLen;
+
+  // device images of the signals: interleaved complex, or the real parts alone for the real-input kinds
+  DeviceArray<__half2> x_cplx, y_cplx;
+  DeviceArray<__half> x_real, y_real;
+  if (cfg.real_input) {
+    std::vector<__half> re(points);
+    for (size_t i = 0; i < points; ++i) re[i] = __low2half(problem.x[i]);
+    x_real.upload(re);
+  } else {
+    x_cplx.upload(problem.x);
   }
-  if (B < 1 || D < 1 || runs < 1 || warmup < 0) {
-    std::cerr << "B, D and runs must be positive\n";
-    return EXIT_FAILURE;
-  }
+  if (kind == TFFT_CONV_REAL_IN_OUT) y_real.resize(points); else y_cplx.resize(points);
+  const void* x_dev = cfg.real_input ? static_cast<const void*>(x_real.get()) : static_cast<const void*>(x_cplx.get());
+  void* y_dev = kind == TFFT_CONV_REAL_IN_OUT ? static_cast<void*>(y_real.get()) : static_cast<void*>(y_cplx.get());
 
-  CHECK_HIP(hipSetDevice(device));
-  // tuning knobs outside the reference's argument list
-  if (const char* e = std::getenv("TFFT_CONV_RESIDENT_PER_CU")) tfft_set_option("conv_resident_per_cu", std::atoi(e));
-  if (const char* e = std::getenv("TFFT_MODE")) tfft_set_option("mode", std::atoi(e));
-  std::srand(42);
+  thunderfft::ThunderFFTInitialize<__half>(kLen);
+  FilterSpectra filters(cfg, problem, opt);
+  if (!cfg.filter_in_loop) filters.prepare();
 
-  const int batch_count = B * D;
-  const size_t sig_elems = size_t(batch_count) * kN;
-  const size_t filt_elems = size_t(D) * kN;
+  const float ms = harness::mean_ms(
+      [&] {
+        if (cfg.filter_in_loop) filters.prepare();
+        harness::tfft_ok(tfft_conv_exec_opt(TFFT_F16, kLen, kind, x_dev, filters.permuted(), y_dev, cfg.B, cfg.D, nullptr, &opt),
+                         "fused convolution");
+      },
+      cfg.warmup, cfg.runs);
 
-  std::vector<cpx_h> h_x(sig_elems);
-  std::vector<__half> h_x_real(sig_elems, __float2half(0.0f));
-  std::vector<float2> h_h_time(filt_elems, make_float2(0.f, 0.f));
-  std::vector<cpx_h> h_h_half(filt_elems, __float2half2_rn(0.0f));
-  for (size_t i = 0; i < sig_elems; ++i) {
-    const float re = std::rand() / float(RAND_MAX);
-    const float im = real_input ? 0.0f : (std::rand() / float(RAND_MAX));
-    h_x[i] = __floats2half2_rn(re, im);
-    h_x_real[i] = __float2half(re);
-  }
-  for (int d = 0; d < D; ++d) {
-    for (int k = 0; k < K; ++k) {
-      // taps scaled by 1/N: the unnormalised inverse then returns linear amplitude, and the
-      // product in the frequency domain stays inside the fp16 range
-      const float re = (std::rand() / float(RAND_MAX)) / float(kN);
-      const float im = real_filter ? 0.0f : ((std::rand() / float(RAND_MAX)) / float(kN));
-      h_h_time[size_t(d) * kN + k] = make_float2(re, im);
-      h_h_half[size_t(d) * kN + k] = __floats2half2_rn(re, im);
-    }
-  }
-
-  cpx_h *d_x = nullptr, *d_out = nullptr, *d_H = nullptr, *d_H_perm = nullptr, *d_h_half = nullptr;
-  __half *d_x_real = nullptr, *d_out_real = nullptr;
-  float2 *d_h_time = nullptr, *d_h_freq = nullptr;
-  CHECK_HIP(hipMalloc(&d_x, sizeof(cpx_h) * sig_elems));
-  CHECK_HIP(hipMalloc(&d_out, sizeof(cpx_h) * sig_elems));
-  CHECK_HIP(hipMalloc(&d_H, sizeof(cpx_h) * filt_elems));
-  CHECK_HIP(hipMalloc(&d_H_perm, sizeof(cpx_h) * filt_elems));
-  CHECK_HIP(hipMalloc(&d_h_half, sizeof(cpx_h) * filt_elems));
-  CHECK_HIP(hipMalloc(&d_h_time, sizeof(float2) * filt_elems));
-  CHECK_HIP(hipMalloc(&d_h_freq, sizeof(float2) * filt_elems));
-  if (real_input) {
-    CHECK_HIP(hipMalloc(&d_x_real, sizeof(__half) * sig_elems));
-    CHECK_HIP(hipMemcpy(d_x_real, h_x_real.data(), sizeof(__half) * sig_elems, hipMemcpyHostToDevice));
-  }
-  if (real_input && real_filter) CHECK_HIP(hipMalloc(&d_out_real, sizeof(__half) * sig_elems));
-  CHECK_HIP(hipMemcpy(d_x, h_x.data(), sizeof(cpx_h) * sig_elems, hipMemcpyHostToDevice));
-  CHECK_HIP(hipMemcpy(d_h_time, h_h_time.data(), sizeof(float2) * filt_elems, hipMemcpyHostToDevice));
-  CHECK_HIP(hipMemcpy(d_h_half, h_h_half.data(), sizeof(cpx_h) * filt_elems, hipMemcpyHostToDevice));
-
-  hipfftHandle plan_h;
-  CHECK_HIPFFT(hipfftPlan1d(&plan_h, kN, HIPFFT_C2C, D));
-  thunderfft::ThunderFFTInitialize<__half>(kN);
-
-  auto filter_fft_once = [&]() {
-    if (filter_fft_mode == 0) {
-      CHECK_HIPFFT(hipfftExecC2C(plan_h, reinterpret_cast<hipfftComplex*>(d_h_time),
-                                 reinterpret_cast<hipfftComplex*>(d_h_freq), HIPFFT_FORWARD));
-      f32_to_h2<<<dim3((unsigned)((filt_elems + 255) / 256)), dim3(256)>>>(d_h_freq, d_H, (int)filt_elems);
-      CHECK_HIP(hipGetLastError());
-    } else {
-      check_tfft(tfft_exec_c2c(TFFT_F16, kN, 1, d_h_half, d_H, D, nullptr), "filter transform");
-    }
-    check_tfft(tfft_conv_filter_layout(TFFT_F16, kN, d_H, d_H_perm, D, nullptr), "filter layout");
-  };
-
-  if (!include_filter_fft) {
-    filter_fft_once();
-    CHECK_HIP(hipDeviceSynchronize());
-  }
-
-  const int kind = real_input ? (real_filter ? TFFT_CONV_REAL_IN_OUT : TFFT_CONV_REAL_IN) : TFFT_CONV_COMPLEX;
-  const void* x_arg = real_input ? static_cast<const void*>(d_x_real) : static_cast<const void*>(d_x);
-  void* y_arg = (kind == TFFT_CONV_REAL_IN_OUT) ? static_cast<void*>(d_out_real) : static_cast<void*>(d_out);
-  auto run_once = [&]() {
-    if (include_filter_fft) filter_fft_once();
-    check_tfft(tfft_conv_exec(TFFT_F16, kN, kind, x_arg, d_H_perm, y_arg, B, D, nullptr), "fused convolution");
-  };
-
-  const float ms = measure_execution_ms(run_once, unsigned(warmup), unsigned(runs));
   std::cout << std::fixed << std::setprecision(6) << "ThunderFFT full FFT-Conv (N=4096, include_filter_fft="
-            << include_filter_fft << ", filter_fft_mode=" << filter_fft_mode << ") time: " << ms << " ms\n";
+            << cfg.filter_in_loop << ", filter_fft_mode=" << cfg.filter_fft_mode << ") time: " << ms << " ms\n";
   {
-    // not in the reference's output: compulsory HBM bytes of the signal pass and the rate they moved at
-    const double in_b = real_input ? 2.0 : 4.0, out_b = (kind == TFFT_CONV_REAL_IN_OUT) ? 2.0 : 4.0;
-    const double bytes = double(sig_elems) * (in_b + out_b) + double(filt_elems) * 4.0;
-    const double flops = 2.0 * 5.0 * kN * 12.0 * batch_count;
-    std::cout << std::setprecision(3) << "  signals=" << batch_count << " bytes=" << bytes / 1e6 << " MB  "
-              << bytes / (ms * 1e-3) / 1e9 << " GB/s (" << 100.0 * bytes / (ms * 1e-3) / 8e12 << "% of 8 TB/s)  "
-              << flops / (ms * 1e-3) / 1e12 << " TFLOP/s (2 x 5NlogN per signal)\n";
+    // beyond the contract: compulsory HBM bytes of the signal pass (signals in + out, filter spectra once)
+    const double in_bytes = cfg.real_input ? 2.0 : 4.0, out_bytes = kind == TFFT_CONV_REAL_IN_OUT ? 2.0 : 4.0;
+    const double bytes = (double)points * (in_bytes + out_bytes) + 4.0 * cfg.D * kLen;
+    const double flops = 2.0 * 5.0 * kLen * 12.0 * (double)cfg.signals();
+    const double sec = ms * 1e-3;
+    std::cout << std::setprecision(3) << "  signals=" << cfg.signals() << " bytes=" << bytes / 1e6 << " MB  "
+              << bytes / sec / 1e9 << " GB/s (" << 100.0 * bytes / sec / 8e12 << "% of 8 TB/s)  " << flops / sec / 1e12
+              << " TFLOP/s (2 x 5NlogN per signal)\n";
   }
 
-  if (validate) {
-    std::vector<cpx_h> h_out(sig_elems);
+  if (cfg.validate) {
+    // every signal when there are few, else 64 of them spread over the batch (the direct sums cost N*K each)
+    std::vector<size_t> sample;
+    const size_t total = cfg.signals(), want = std::min<size_t>(total, 64);
+    for (size_t i = 0; i < want; ++i) sample.push_back(i * total / want);
+    std::vector<cplx> y(sample.size() * kLen);
     if (kind == TFFT_CONV_REAL_IN_OUT) {
-      std::vector<__half> h_out_real(sig_elems);
-      CHECK_HIP(hipMemcpy(h_out_real.data(), d_out_real, sizeof(__half) * sig_elems, hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < sig_elems; ++i) h_out[i] = __halves2half2(h_out_real[i], __float2half(0.0f));
+      const std::vector<__half> host = y_real.download();
+      for (size_t s = 0; s < sample.size(); ++s)
+        for (int n = 0; n < kLen; ++n) y[s * kLen + n] = cplx(__half2float(host[sample[s] * kLen + n]), 0.0);
     } else {
-      CHECK_HIP(hipMemcpy(h_out.data(), d_out, sizeof(cpx_h) * sig_elems, hipMemcpyDeviceToHost));
+      const std::vector<__half2> host = y_cplx.download();
+      for (size_t s = 0; s < sample.size(); ++s)
+        for (int n = 0; n < kLen; ++n) y[s * kLen + n] = harness::to_cplx(host[sample[s] * kLen + n]);
     }
-    double max_raw = 0.0, max_scaled = 0.0, max_corr = 0.0;
-    double num_raw = 0.0, num_scaled = 0.0, den = 0.0, num_corr = 0.0, den_corr = 0.0;
-    for (int bd = 0; bd < batch_count; ++bd) {
-      const int d = bd % D;
-      for (int n = 0; n < kN; ++n) {
-        float ref_re = 0.f, ref_im = 0.f, refc_re = 0.f, refc_im = 0.f;
-        for (int kk = 0; kk < K; ++kk) {
-          const float2 hv = h_h_time[size_t(d) * kN + kk];
-          const int xi = (n - kk >= 0) ? n - kk : n - kk + kN;
-          const float2 xv = __half22float2(h_x[size_t(bd) * kN + xi]);
-          ref_re += xv.x * hv.x - xv.y * hv.y;
-          ref_im += xv.x * hv.y + xv.y * hv.x;
-          const int xic = (n + kk < kN) ? n + kk : n + kk - kN;
-          const float2 xc = __half22float2(h_x[size_t(bd) * kN + xic]);
-          refc_re += xc.x * hv.x - xc.y * hv.y;
-          refc_im += xc.x * hv.y + xc.y * hv.x;
-        }
-        const float2 ov = __half22float2(h_out[size_t(bd) * kN + n]);
-        auto acc = [](float dx, float dy, double& mx, double& num) {
-          const double a2 = double(dx) * dx + double(dy) * dy;
-          mx = std::max(mx, std::sqrt(a2));
-          num += a2;
-        };
-        acc(ov.x - ref_re, ov.y - ref_im, max_raw, num_raw);
-        acc(ov.x / float(kN) - ref_re, ov.y / float(kN) - ref_im, max_scaled, num_scaled);
-        acc(ov.x / float(kN) - refc_re, ov.y / float(kN) - refc_im, max_corr, num_corr);
-        den += double(ref_re) * ref_re + double(ref_im) * ref_im;
-        den_corr += double(refc_re) * refc_re + double(refc_im) * refc_im;
-      }
-    }
-    auto rel = [](double num, double d) { return d > 0.0 ? std::sqrt(num / d) : std::sqrt(num); };
-    std::cout << std::setprecision(6) << "Validation vs direct circular conv (raw): L2_rel=" << rel(num_raw, den)
-              << " max_abs=" << max_raw << "\n"
-              << "Validation vs direct circular conv (raw/N): L2_rel=" << rel(num_scaled, den)
-              << " max_abs=" << max_scaled << "\n"
-              << "Validation vs direct circular corr (raw/N): L2_rel=" << rel(num_corr, den_corr)
-              << " max_abs=" << max_corr << "\n";
+    const Validation v = validate(cfg, problem, y, sample);
+    std::cout << std::setprecision(6) << "Validation vs direct circular conv (raw): L2_rel=" << v.raw.l2_rel()
+              << " max_abs=" << v.raw.max_diff << "\n"
+              << "Validation vs direct circular conv (raw/N): L2_rel=" << v.scaled.l2_rel()
+              << " max_abs=" << v.scaled.max_diff << "\n"
+              << "Validation vs direct circular corr (raw/N): L2_rel=" << v.corr.l2_rel()
+              << " max_abs=" << v.corr.max_diff << "\n"
+              << "  (" << v.checked << " of " << total << " signals checked, fp64 sums)\n";
   }
-
   thunderfft::ThunderFFTFinalize<__half>();
-  CHECK_HIPFFT(hipfftDestroy(plan_h));
-  CHECK_HIP(hipFree(d_x));
-  CHECK_HIP(hipFree(d_out));
-  CHECK_HIP(hipFree(d_H));
-  CHECK_HIP(hipFree(d_H_perm));
-  CHECK_HIP(hipFree(d_h_half));
-  CHECK_HIP(hipFree(d_h_time));
-  CHECK_HIP(hipFree(d_h_freq));
-  if (d_x_real) CHECK_HIP(hipFree(d_x_real));
-  if (d_out_real) CHECK_HIP(hipFree(d_out_real));
   return 0;
 }

@@ -1,110 +1,73 @@
-// Minimal forward-transform sample: the MI355X build of the reference's thff_fft
-// (thunderfft/sample/fft1d/main.cu:74-163). Same call sequence on the same template API
-// (ThunderFFTInitialize<float>(N), ThunderFFT_global<float, N, true>(d_in, d_out, batch, stream),
-// ThunderFFTFinalize<float>()), same bin-aligned test tones (:16-30), checksum (:35-43) and report
-// lines; hipFFT stands where the reference compares with cuFFT (:119-128).
-// N is a compile-time constant as in the reference (:76): build with -DTHFF_FFT_N=<N> to change it.
+// thff_fft for MI355X: the smallest user of the public template API,
+//   ThunderFFTInitialize<float>(N); ThunderFFT_global<float, N, true>(in, out, batch, stream); ThunderFFTFinalize<float>();
+// on the reference sample's workload and report (thunderfft/sample/fft1d/main.cu:74-163): N = 64 at compile
+// time (-DTHFF_FFT_N=<N> changes it), 65536 transforms, transform b holding a tone of amplitude 0.5 + 0.1 b on
+// bin 1 + b plus 0.1 on bin 7 (:16-30), compared with the vendor library (hipFFT here, cuFFT there) by
+// relative L2 and L-infinity error, plus a weighted checksum and the first bins of transform 0.
 #include <hipfft/hipfft.h>
 
 #include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
 #include <iomanip>
 #include <iostream>
-#include <vector>
 
-#include <thunderfft/thunderfft.cuh>
+#include "harness.hpp"
 
 #ifndef THFF_FFT_N
 #define THFF_FFT_N 64
 #endif
 
 int main() {
+  using harness::cplx;
   constexpr unsigned N = THFF_FFT_N;
   const unsigned batch = 65536;
   const int device = 0;
-  CHECK_HIP(hipSetDevice(device));
+  harness::hip_ok(hipSetDevice(device), "hipSetDevice");
   std::cout << "ThunderFFT vs hipFFT\n"
             << "  Type   : float/float2\n"
             << "  N      : " << N << " (compile-time)\n"
             << "  batch  : " << batch << "\n"
             << "  device : " << device << "\n";
 
-  const size_t count = size_t(N) * batch;
-  const size_t bytes = sizeof(float2) * count;
-  std::vector<float2> h_in(count), h_out(count), h_ref(count);
-  // transform b: a tone of amplitude 0.5 + 0.1 b on bin 1 + b, plus 0.1 on bin 7
-  const float two_pi = 2.0f * float(M_PI);
-  for (unsigned b = 0; b < batch; ++b) {
-    const float f0 = float(1 + b), amp = 0.5f + 0.1f * float(b);
+  // bin-aligned tones, evaluated in fp64 and rounded once
+  std::vector<float2> tones((size_t)N * batch);
+  for (unsigned b = 0; b < batch; ++b)
     for (unsigned i = 0; i < N; ++i) {
-      const float t = float(i) / float(N);
-      h_in[size_t(b) * N + i] = make_float2(amp * std::cos(two_pi * f0 * t) + 0.1f * std::cos(two_pi * 7.0f * t),
-                                            amp * std::sin(two_pi * f0 * t) + 0.1f * std::sin(two_pi * 7.0f * t));
+      const double t = 2.0 * M_PI * (double)i / N;
+      const cplx v = std::polar(0.5 + 0.1 * b, t * (double)(1 + b)) + std::polar(0.1, t * 7.0);
+      tones[(size_t)b * N + i] = make_float2((float)v.real(), (float)v.imag());
     }
-  }
-
-  float2 *d_in = nullptr, *d_out = nullptr, *d_ref = nullptr;
-  CHECK_HIP(hipMalloc(&d_in, bytes));
-  CHECK_HIP(hipMalloc(&d_out, bytes));
-  CHECK_HIP(hipMalloc(&d_ref, bytes));
-  CHECK_HIP(hipMemcpy(d_in, h_in.data(), bytes, hipMemcpyHostToDevice));
+  harness::DeviceArray<float2> d_in, d_ours(tones.size()), d_vendor(tones.size());
+  d_in.upload(tones);
 
   thunderfft::ThunderFFTInitialize<float>(N);
-  // one warm-up, the mean of five calls (each returns after the stream has drained, like the reference's)
-  const unsigned warm_up_runs = 1, runs = 5;
-  hipEvent_t e0, e1;
-  CHECK_HIP(hipEventCreate(&e0));
-  CHECK_HIP(hipEventCreate(&e1));
-  for (unsigned i = 0; i < warm_up_runs; ++i) thunderfft::ThunderFFT_global<float, N, true>(d_in, d_out, batch, 0);
-  CHECK_HIP(hipDeviceSynchronize());
-  CHECK_HIP(hipEventRecord(e0));
-  for (unsigned i = 0; i < runs; ++i) thunderfft::ThunderFFT_global<float, N, true>(d_in, d_out, batch, 0);
-  CHECK_HIP(hipEventRecord(e1));
-  CHECK_HIP(hipDeviceSynchronize());
-  float ms_tf = 0.f;
-  CHECK_HIP(hipEventElapsedTime(&ms_tf, e0, e1));
-  ms_tf /= float(runs);
-  CHECK_HIP(hipMemcpy(h_out.data(), d_out, bytes, hipMemcpyDeviceToHost));
+  // every call returns after the stream has drained, like the reference's launcher
+  const float ms = harness::mean_ms([&] { thunderfft::ThunderFFT_global<float, N, true>(d_in.get(), d_ours.get(), batch, 0); }, 1, 5);
 
   hipfftHandle plan{};
-  if (hipfftPlan1d(&plan, int(N), HIPFFT_C2C, int(batch)) != HIPFFT_SUCCESS ||
-      hipfftExecC2C(plan, reinterpret_cast<hipfftComplex*>(d_in), reinterpret_cast<hipfftComplex*>(d_ref),
-                    HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
-    std::fprintf(stderr, "hipFFT failed\n");
-    return EXIT_FAILURE;
-  }
-  CHECK_HIP(hipDeviceSynchronize());
-  CHECK_HIP(hipMemcpy(h_ref.data(), d_ref, bytes, hipMemcpyDeviceToHost));
+  if (hipfftPlan1d(&plan, (int)N, HIPFFT_C2C, (int)batch) != HIPFFT_SUCCESS ||
+      hipfftExecC2C(plan, reinterpret_cast<hipfftComplex*>(d_in.get()), reinterpret_cast<hipfftComplex*>(d_vendor.get()),
+                    HIPFFT_FORWARD) != HIPFFT_SUCCESS)
+    harness::die("hipFFT failed");
+  harness::hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  const std::vector<float2> ours = d_ours.download(), vendor = d_vendor.download();
 
-  long double num = 0.0L, den = 0.0L, max_diff = 0.0L, max_ref = 0.0L, acc = 0.0L;
-  for (size_t i = 0; i < count; ++i) {
-    const long double dx = (long double)h_out[i].x - h_ref[i].x, dy = (long double)h_out[i].y - h_ref[i].y;
-    num += dx * dx + dy * dy;
-    den += (long double)h_ref[i].x * h_ref[i].x + (long double)h_ref[i].y * h_ref[i].y;
-    max_diff = std::max(max_diff, std::hypot(dx, dy));
-    max_ref = std::max(max_ref, std::hypot((long double)h_ref[i].x, (long double)h_ref[i].y));
-    acc += (long double)h_out[i].x * 1.0001L + (long double)h_out[i].y * 0.9997L;
+  harness::ErrorSums err;
+  long double checksum = 0.0L;
+  for (size_t i = 0; i < ours.size(); ++i) {
+    err.add(harness::to_cplx(ours[i]), harness::to_cplx(vendor[i]));
+    checksum += (long double)ours[i].x * 1.0001L + (long double)ours[i].y * 0.9997L;
   }
-  const double err_l2 = den > 0 ? (double)std::sqrt((double)(num / den)) : (double)std::sqrt((double)num);
-  const double err_linf = max_ref > 0 ? (double)(max_diff / max_ref) : (double)max_diff;
-
-  std::cout << std::fixed << std::setprecision(6);
-  std::cout << "ThunderFFT avg time : " << ms_tf << " ms\n";
-  std::cout << "Checksum(ThunderFFT): " << (double)acc << "\n";
-  std::cout << "Compare vs hipFFT   : L2_rel=" << std::setprecision(3) << std::scientific << err_l2
-            << "  Linf_rel=" << err_linf << std::fixed << std::setprecision(6) << "\n";
-  const unsigned to_print = std::min<unsigned>(8, N);
-  std::cout << "First " << to_print << " bins (batch 0):\n";
-  for (unsigned i = 0; i < to_print; ++i)
-    std::cout << "  k=" << std::setw(3) << i << "  TF=(" << h_out[i].x << ", " << h_out[i].y << ")"
-              << "  hipFFT=(" << h_ref[i].x << ", " << h_ref[i].y << ")\n";
+  std::cout << std::fixed << std::setprecision(6) << "ThunderFFT avg time : " << ms << " ms\n"
+            << "Checksum(ThunderFFT): " << (double)checksum << "\n"
+            << "Compare vs hipFFT   : L2_rel=" << std::setprecision(3) << std::scientific << err.l2_rel()
+            << "  Linf_rel=" << err.linf_rel() << std::fixed << std::setprecision(6) << "\n";
+  const unsigned shown = std::min<unsigned>(8, N);
+  std::cout << "First " << shown << " bins (batch 0):\n";
+  for (unsigned k = 0; k < shown; ++k)
+    std::cout << "  k=" << std::setw(3) << k << "  TF=(" << ours[k].x << ", " << ours[k].y << ")"
+              << "  hipFFT=(" << vendor[k].x << ", " << vendor[k].y << ")\n";
 
   thunderfft::ThunderFFTFinalize<float>();
   hipfftDestroy(plan);
-  CHECK_HIP(hipFree(d_in));
-  CHECK_HIP(hipFree(d_out));
-  CHECK_HIP(hipFree(d_ref));
   return 0;
 }

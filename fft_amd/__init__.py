@@ -15,6 +15,9 @@ from .api import (  # noqa: F401
     is_supported,
     plan_info,
     set_option,
+    exec_options,
+    workspace_bytes,
+    bench_access_pattern,
     fft,
     SUPPORTED_N,
 )

@@ -10,12 +10,19 @@ SYMBOLS = (
     "tfft_initialize",
     "tfft_finalize",
     "tfft_exec_c2c",
+    "tfft_exec_c2c_opt",
+    "tfft_exec_c2c_static",
+    "tfft_exec_options_init",
+    "tfft_workspace_bytes",
+    "tfft_bench_access_pattern",
     "tfft_is_supported",
     "tfft_get_plan_info",
     "tfft_set_option",
     "tfft_fourstep_twiddle",
     "tfft_conv_exec",
+    "tfft_conv_exec_opt",
     "tfft_conv_filter_layout",
+    "tfft_conv_filter_layout_opt",
     "tfft_conv_tiles_exec",
     "tfft_get_twiddle_table",
     "tfft_last_error",
@@ -31,6 +38,21 @@ class PlanInfo(ctypes.Structure):
         ("radix", ctypes.c_int * 3),
         ("lds_bytes", ctypes.c_int),
         ("blocks_per_cu", ctypes.c_int),
+    ]
+
+
+class ExecOptions(ctypes.Structure):
+    """tfft_exec_options of include/thunderfft_c.h."""
+    _fields_ = [
+        ("struct_size", ctypes.c_int),
+        ("plan", ctypes.c_int),
+        ("xcd_run_log2", ctypes.c_int),
+        ("grid_blocks_per_cu", ctypes.c_int),
+        ("grid_blocks", ctypes.c_longlong),
+        ("extra_lds", ctypes.c_int),
+        ("reserved", ctypes.c_int),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_ulonglong),
     ]
 
 
@@ -55,6 +77,16 @@ def load():
     lib.tfft_initialize.argtypes = [i, i]
     lib.tfft_finalize.argtypes = [i]
     lib.tfft_exec_c2c.argtypes = [i, i, i, vp, vp, ll, vp]
+    op = ctypes.POINTER(ExecOptions)
+    ullp = ctypes.POINTER(ctypes.c_ulonglong)
+    lib.tfft_exec_c2c_opt.argtypes = [i, i, i, vp, vp, ll, vp, op]
+    lib.tfft_exec_c2c_static.argtypes = [i, i, i, vp, vp, ll, vp]
+    lib.tfft_exec_options_init.argtypes = [op]
+    lib.tfft_exec_options_init.restype = None
+    lib.tfft_workspace_bytes.argtypes = [i, i, ll, ullp, ullp]
+    lib.tfft_bench_access_pattern.argtypes = [i, i, i, i, vp, vp, ll, vp, op]
+    lib.tfft_conv_exec_opt.argtypes = [i, i, i, vp, vp, vp, i, i, vp, op]
+    lib.tfft_conv_filter_layout_opt.argtypes = [i, i, vp, vp, i, vp, op]
     lib.tfft_is_supported.argtypes = [i, i, i]
     lib.tfft_get_plan_info.argtypes = [i, i, ctypes.POINTER(PlanInfo)]
     lib.tfft_set_option.argtypes = [cp, ll]
@@ -66,7 +98,7 @@ def load():
     lib.tfft_last_error.argtypes = []
     lib.tfft_last_error.restype = cp
     for name in SYMBOLS:
-        if name != "tfft_last_error":
+        if name not in ("tfft_last_error", "tfft_exec_options_init"):
             getattr(lib, name).restype = i
     _lib = lib
     return lib

@@ -74,7 +74,38 @@ def plan_info(dtype, N):
 
 
 def set_option(key, value):
+    """Process-wide switch; the only key is "sync" (block after every launch like the reference)."""
     _check(_lib.load().tfft_set_option(key.encode(), int(value)))
+
+
+def exec_options(options):
+    """dict of per-call launch options -> a filled tfft_exec_options (None stays None = defaults).
+
+    Keys: plan, xcd_run_log2, grid_blocks_per_cu, grid_blocks, extra_lds, workspace (a device tensor used as the
+    scratch of a multi-pass transform)."""
+    if not options:
+        return None
+    o = _lib.ExecOptions()
+    _lib.load().tfft_exec_options_init(o)
+    for key, value in options.items():
+        if key == "workspace":
+            if value is not None:
+                o.workspace = value.data_ptr()
+                o.workspace_bytes = value.numel() * value.element_size()
+        elif key in ("plan", "xcd_run_log2", "grid_blocks_per_cu", "grid_blocks", "extra_lds"):
+            setattr(o, key, int(value))
+        else:
+            raise ThunderFFTError(3, f"unknown launch option '{key}'")
+    return o
+
+
+def workspace_bytes(dtype, N, batch=1):
+    """(minimum, best) scratch bytes of a multi-pass transform; (0, 0) for lengths one kernel handles."""
+    import ctypes
+
+    lo, best = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+    _check(_lib.load().tfft_workspace_bytes(dtype_code(dtype), int(N), int(batch), lo, best))
+    return lo.value, best.value
 
 
 def _points(t, N):
@@ -90,11 +121,12 @@ def _points(t, N):
     return pts, code
 
 
-def ThunderFFT_global(d_input, d_output, batch, N, forward=True, stream=None):
+def ThunderFFT_global(d_input, d_output, batch, N, forward=True, stream=None, options=None):
     """Launch `batch` transforms of length N from d_input to d_output (may be the same tensor).
 
     Tensors are complex64 [batch, N], or float32 / float16 / bfloat16 [batch, N, 2] with
     interleaved (re, im). Asynchronous on `stream` (default: torch's current stream).
+    `options`: per-call launch options (see exec_options); every choice gives the same results.
     """
     pts_in, code = _points(d_input, N)
     pts_out, code_out = _points(d_output, N)
@@ -105,8 +137,26 @@ def ThunderFFT_global(d_input, d_output, batch, N, forward=True, stream=None):
     if stream is None:
         stream = torch.cuda.current_stream(d_input.device)
     with torch.cuda.device(d_input.device):
-        _check(_lib.load().tfft_exec_c2c(code, int(N), int(bool(forward)), d_input.data_ptr(),
-                                         d_output.data_ptr(), int(batch), stream.cuda_stream))
+        if options:
+            _check(_lib.load().tfft_exec_c2c_opt(code, int(N), int(bool(forward)), d_input.data_ptr(),
+                                                 d_output.data_ptr(), int(batch), stream.cuda_stream,
+                                                 exec_options(options)))
+        else:
+            _check(_lib.load().tfft_exec_c2c(code, int(N), int(bool(forward)), d_input.data_ptr(),
+                                             d_output.data_ptr(), int(batch), stream.cuda_stream))
+    return d_output
+
+
+def bench_access_pattern(d_input, d_output, batch, N, pattern, forward=True, stream=None, options=None):
+    """MEASUREMENT ONLY (the output is meaningless): the default kernel of (dtype, N) with its arithmetic
+    (pattern 1) or its LDS exchanges (pattern 2) compiled out. See tfft_bench_access_pattern."""
+    _, code = _points(d_input, N)
+    if stream is None:
+        stream = torch.cuda.current_stream(d_input.device)
+    with torch.cuda.device(d_input.device):
+        _check(_lib.load().tfft_bench_access_pattern(code, int(N), int(bool(forward)), int(pattern),
+                                                     d_input.data_ptr(), d_output.data_ptr(), int(batch),
+                                                     stream.cuda_stream, exec_options(options)))
     return d_output
 
 

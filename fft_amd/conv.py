@@ -8,7 +8,7 @@ The same two steps are `filter_spectra` and `fft_conv` here; tensors stand in fo
 import torch
 
 from . import _lib
-from .api import ThunderFFTError, ThunderFFTInitialize, ThunderFFT_global, _check, dtype_code
+from .api import ThunderFFTError, ThunderFFTInitialize, ThunderFFT_global, _check, dtype_code, exec_options
 
 CONV_COMPLEX, CONV_REAL_IN, CONV_REAL_IN_OUT = 0, 1, 2
 SUPPORTED_CONV_N = (4096,)
@@ -18,19 +18,21 @@ def _stream(t, stream):
     return (stream or torch.cuda.current_stream(t.device)).cuda_stream
 
 
-def filter_layout(h_freq, N, stream=None):
-    """[D, N, 2] natural-order filter spectra -> the register order the fused kernel reads."""
+def filter_layout(h_freq, N, stream=None, options=None):
+    """[D, N, 2] natural-order filter spectra -> the register order the fused kernel reads (the kernel that
+    `options` selects: pass the same options to fft_conv)."""
     if not (h_freq.is_cuda and h_freq.is_contiguous()) or h_freq.shape[-2:] != (N, 2):
         raise ThunderFFTError(3, "filter_layout needs a contiguous device tensor [D, N, 2]")
     D = h_freq.numel() // (2 * N)
     out = torch.empty_like(h_freq)
     with torch.cuda.device(h_freq.device):
-        _check(_lib.load().tfft_conv_filter_layout(dtype_code(h_freq.dtype), int(N), h_freq.data_ptr(),
-                                                   out.data_ptr(), int(D), _stream(h_freq, stream)))
+        _check(_lib.load().tfft_conv_filter_layout_opt(dtype_code(h_freq.dtype), int(N), h_freq.data_ptr(),
+                                                       out.data_ptr(), int(D), _stream(h_freq, stream),
+                                                       exec_options(options)))
     return out
 
 
-def filter_spectra(h_time, N, stream=None):
+def filter_spectra(h_time, N, stream=None, options=None):
     """Filter taps [D, K, 2] (already scaled by 1/N if the caller wants a normalised result, as the
     reference does at :352-361) -> register-order spectra [D, N, 2] of the same element type."""
     D, K = h_time.shape[0], h_time.shape[1]
@@ -41,10 +43,10 @@ def filter_spectra(h_time, N, stream=None):
     ThunderFFTInitialize(h_time.dtype, N)
     spec = torch.empty_like(padded)
     ThunderFFT_global(padded, spec, D, N, True, stream)
-    return filter_layout(spec, N, stream)
+    return filter_layout(spec, N, stream, options)
 
 
-def fft_conv(x, h_perm, N, kind=CONV_COMPLEX, out=None, stream=None):
+def fft_conv(x, h_perm, N, kind=CONV_COMPLEX, out=None, stream=None, options=None):
     """y[b, d] = IDFT_N(DFT_N(x[b, d]) * H[d]), unnormalised, in one kernel.
 
     x: [B, D, N, 2] (complex kinds) or [B, D, N] (real-input kinds); h_perm from filter_spectra /
@@ -62,8 +64,9 @@ def fft_conv(x, h_perm, N, kind=CONV_COMPLEX, out=None, stream=None):
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     ThunderFFTInitialize(x.dtype, N)
     with torch.cuda.device(x.device):
-        _check(_lib.load().tfft_conv_exec(dtype_code(x.dtype), int(N), int(kind), x.data_ptr(), h_perm.data_ptr(),
-                                          out.data_ptr(), int(B), int(D), _stream(x, stream)))
+        _check(_lib.load().tfft_conv_exec_opt(dtype_code(x.dtype), int(N), int(kind), x.data_ptr(), h_perm.data_ptr(),
+                                              out.data_ptr(), int(B), int(D), _stream(x, stream),
+                                              exec_options(options)))
     return out
 
 

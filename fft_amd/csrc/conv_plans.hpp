@@ -11,15 +11,19 @@ enum : int { kConvComplex = 0, kConvRealIn = 1, kConvRealInOut = 2 };
 
 struct ConvEntry {
   // y[b][d] = IDFT_n( DFT_n(x[b][d]) * H[d] ), unnormalised; hp = H in the kernel's register order
-  void (*launch)(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream);
+  // resident_per_cu > 0: a resident grid of that many workgroups per CU (matrix-core kernels only; others ignore it)
+  void (*launch)(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int resident_per_cu,
+                 hipStream_t stream);
   // hp <- h: natural-order spectra [D][n] to register order
   void (*layout)(const void* h, void* hp, int D, hipStream_t stream);
   int n, threads, points_per_thread, lds_bytes;
+  int layout_id;  // which register order `layout` writes and `launch` reads (kConvLayout*)
 };
+enum : int { kConvLayoutValu = 1, kConvLayoutMfma = 2 };
 
-// mode 0: the default kernel of (dtype, n, kind); mode 3: the fp32-VALU kernel where the default runs on the
-// matrix cores (fp16 storage). Filter layout and execution must be looked up with the same mode.
-bool lookup_conv(int dtype, int n, int kind, int mode, ConvEntry* out);
+// plan 0: the default kernel of (dtype, n, kind); plan 3: the fp32-VALU kernel where the default runs on the
+// matrix cores (fp16 storage). The two read the permuted filters in different orders (layout_id).
+bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out);
 
 // Overlap-save tiles of length n, `valid` outputs kept per tile.
 struct ConvTilesEntry {
@@ -28,8 +32,5 @@ struct ConvTilesEntry {
   int n, threads, tiles_per_block;
 };
 bool lookup_conv_tiles(int dtype, int n, ConvTilesEntry* out);
-
-// Tuning: workgroups per CU of the matrix-core convolution's resident grid (0: one workgroup per work item).
-void set_conv_mfma_resident_per_cu(int v);
 
 }  // namespace tfft

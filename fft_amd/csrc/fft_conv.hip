@@ -37,9 +37,9 @@ __global__ __launch_bounds__(P::WG) void conv_filter_layout_kernel(const typenam
 }
 
 template <class P, class IOIN, class IOOUT, class HIO>
-__global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_kernel(const typename IOIN::raw* __restrict__ x,
+__global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_kernel(const typename IOIN::raw* x,  // x and y may alias
                                                                   const typename HIO::raw* __restrict__ hp,
-                                                                  typename IOOUT::raw* __restrict__ y,
+                                                                  typename IOOUT::raw* y,
                                                                   const float2* __restrict__ tw, int B, int D) {
   static_assert(P::TPB == 1, "one signal per workgroup");
   static_assert(BlockFFT<P>::kChainable, "first and last radix must agree");
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_kernel(const typename
 // signal. (A complex filter would mix the two; this kernel is only reached when the caller states
 // that the taps are real.)
 template <class P, class HIO>
-__global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_real_pair_kernel(const unsigned* __restrict__ x,
+__global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_real_pair_kernel(const unsigned* x,  // x and y may alias
                                                                             const typename HIO::raw* __restrict__ hp,
-                                                                            unsigned* __restrict__ y,
+                                                                            unsigned* y,
                                                                             const float2* __restrict__ tw, int B, int D) {
   static_assert(P::TPB == 1 && P::NB1 == 1 && P::NBL == 1, "one signal pair per workgroup, one butterfly per thread");
   static_assert(BlockFFT<P>::kChainable, "first and last radix must agree");
@@ -141,14 +141,14 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_real_pair_kernel(cons
 }
 
 template <class P, class HIO>
-void launch_conv_real_pair(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
+void launch_conv_real_pair(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int, hipStream_t stream) {
   const unsigned npair = ((unsigned)B + 1u) / 2u;
   fft_conv_real_pair_kernel<P, HIO><<<dim3(npair * (unsigned)D), dim3(P::WG), 0, stream>>>(
       static_cast<const unsigned*>(x), static_cast<const typename HIO::raw*>(hp), static_cast<unsigned*>(y), tw, B, D);
 }
 
 template <class P, class IOIN, class IOOUT, class HIO>
-void launch_conv(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
+void launch_conv(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int, hipStream_t stream) {
   fft_conv_kernel<P, IOIN, IOOUT, HIO><<<dim3((unsigned)B * (unsigned)D), dim3(P::WG), 0, stream>>>(
       static_cast<const typename IOIN::raw*>(x), static_cast<const typename HIO::raw*>(hp),
       static_cast<typename IOOUT::raw*>(y), tw, B, D);
@@ -238,6 +238,7 @@ ConvEntry make_conv_entry() {
   ConvEntry e;
   e.launch = &launch_conv<P, IOIN, IOOUT, HIO>;
   e.layout = &launch_layout<P, HIO>;
+  e.layout_id = kConvLayoutValu;
   e.n = P::N;
   e.threads = P::WG;
   e.points_per_thread = P::E;
@@ -265,13 +266,11 @@ bool lookup_conv_plan(int dtype, int kind, ConvEntry* out) {
   return false;
 }
 
-// Workgroups per CU of the resident form (0: one workgroup per work item, the default: at ~190 VGPRs the
+// per_cu: workgroups per CU of the resident form (0: one workgroup per work item, the default: at ~190 VGPRs the
 // resident kernel fits two workgroups per CU and measured 10-15 % slower than one-shot workgroups).
-static int g_conv_mfma_resident_per_cu = 0;
-void set_conv_mfma_resident_per_cu(int v) { g_conv_mfma_resident_per_cu = v; }
-
 template <int KIND>
-void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, int B, int D, hipStream_t stream) {
+void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int per_cu,
+                      hipStream_t stream) {
   const unsigned nb = (KIND == kConvMfmaRealPair) ? ((unsigned)B + 1u) / 2u : (unsigned)B;
   const unsigned items = nb * (unsigned)D;
   static int cus = 0;
@@ -280,7 +279,6 @@ void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, 
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
-  const int per_cu = g_conv_mfma_resident_per_cu;
   if (per_cu > 0 && items > (unsigned)(per_cu * cus)) {
     fft_conv_mfma4096_kernel<KIND, true><<<dim3((unsigned)(per_cu * cus)), dim3(256), 0, stream>>>(
         x, static_cast<const u32x4_t*>(hp), y, tw, B, D);
@@ -295,15 +293,17 @@ void launch_layout_mfma(const void* h, void* hp, int D, hipStream_t stream) {
                                                                                    static_cast<u32x4_t*>(hp), D);
 }
 
-bool lookup_conv(int dtype, int n, int kind, int mode, ConvEntry* out) {
-  if (n != 4096) return false;
-  if (dtype == TFFT_F16 && mode != 3) {
+bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
+  if (n != 4096 || (plan != 0 && plan != 3)) return false;
+  out->layout_id = kConvLayoutValu;
+  if (dtype == TFFT_F16 && plan != 3) {
     // fp16 storage: both transforms on the matrix cores (fft_conv_mfma.hpp)
     out->n = 4096;
     out->threads = 256;
     out->points_per_thread = 16;
     out->lds_bytes = 4 * (Mfma4096::OUT_IMG + Mfma4096::IMG);
     out->layout = &launch_layout_mfma;
+    out->layout_id = kConvLayoutMfma;
     switch (kind) {
       case kConvComplex: out->launch = &launch_conv_mfma<kConvMfmaComplex>; return true;
       case kConvRealIn: out->launch = &launch_conv_mfma<kConvMfmaRealIn>; return true;

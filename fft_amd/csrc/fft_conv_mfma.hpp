@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256) void conv_mfma4096_filter_layout_kernel(const 
 // PERSIST: a resident grid; a workgroup walks work items blockIdx.x, blockIdx.x + gridDim.x, ... and
 // requests the rows of its next item as soon as the current rows are packed into fragments.
 template <int KIND, bool PERSIST>
-__global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel(const void* __restrict__ xv, const u32x4_t* __restrict__ hp,
-                                                                  void* __restrict__ yv, const float2* __restrict__ tw, int B,
+__global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel(const void* xv, const u32x4_t* __restrict__ hp,
+                                                                  void* yv,  // xv and yv may alias
+                                                                  const float2* __restrict__ tw, int B,
                                                                   int D) {
   __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + Mfma4096::IMG];
   unsigned* const img_a = lds;

@@ -324,8 +324,7 @@ constexpr int mfma_out_words() {
 // INCR: the pass-1 twiddles W^(k1 c) of the four columns c0 .. c0 + 3 of a lane are built from W^(k1 c0)
 // and the step W^k1 (32 + 32 bytes of tables per lane instead of 128; 12 more complex multiplications per tile).
 template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false>
-__global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* __restrict__ in,
-                                                                     u32x4_t* __restrict__ out,
+__global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* in, u32x4_t* out,  // in and out may alias (in-place calls)
                                                                      const float2* __restrict__ tw, long long batch,
                                                                      int xcd_log2) {
   static_assert(R1 == 1 || R1 == 2 || R1 == 4 || R1 == 8 || R1 == 16, "N = 256 R1");
@@ -531,7 +530,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 // W^(16 r0 t) and W^(256 r0 r). `tw` holds the N natural-order twiddles followed by the lane-ordered
 // tables of N = 4096.
 template <class T16, bool FWD, int R0, int MINW>
-__global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* __restrict__ in, u32x4_t* __restrict__ out,
+__global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* in, u32x4_t* out,  // in and out may alias
                                                                      const float2* __restrict__ tw, long long batch,
                                                                      int xcd_log2) {
   static_assert(R0 == 2 || R0 == 4, "N = 8192 or 16384");

@@ -6,8 +6,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -21,6 +23,13 @@
 #include "fft_conv_mfma.hpp"
 #include "plans.hpp"
 #include "tile_plans.hpp"
+
+// Scratch of tfft_exec_c2c_static: lives in the code object, so every GPU the library runs on holds its own 8 MiB
+// copy from module load to process exit and no call ever allocates it. In host code the name is a handle for
+// hipGetSymbolAddress only, never an address: each GPU's copy has its own device address, looked up once per
+// device (static_scratch_for) and passed to the kernels like any other buffer.
+constexpr long long kStaticScratchPoints = 1LL << 20;
+static __device__ __align__(256) float4 g_static_scratch[kStaticScratchPoints / 2];
 
 namespace {
 
@@ -59,23 +68,41 @@ struct BigPlan {
   float2* lo[2] = {nullptr, nullptr};
   int shift[2] = {0, 0};
   unsigned long long m[2] = {0, 0};
-  float4* work = nullptr;  // scratch for `work_batch` transforms
+  float4* work = nullptr;  // library-owned scratch for `work_batch` transforms
   long long work_batch = 1;
+  // The scratch is one buffer per (device, n): a call that uses it waits (on the device) for the previous such
+  // call, whatever stream that ran on. `done` is recorded behind the last sweep of every call.
+  hipEvent_t done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool used = false;
 };
 
-struct Options {
+// Per-call launch options after validation (tfft_exec_options in the header).
+struct ExecOpts {
+  int plan = 0;
+  int xcd_run_log2 = -1;
   long long grid_blocks_per_cu = 0;
-  long long mode = 0;
-  long long sync = 0;
-  long long extra_lds = 0;
-  long long grid_blocks = 0;  // absolute resident grid size; overrides grid_blocks_per_cu
-  long long xcd_run_log2 = -1;  // >= 0: runs of 2^value consecutive chunks per XCD instead of the kernel's default
+  long long grid_blocks = 0;
+  int extra_lds = 0;
+  void* workspace = nullptr;
+  unsigned long long workspace_bytes = 0;
 };
 
 std::mutex g_mu;
 std::map<std::tuple<int, int, int>, DevicePlan> g_plans;  // (device, dtype, n)
 std::map<std::tuple<int, int>, BigPlan> g_big;             // (device, n), fp32
-Options g_opt;
+std::atomic<int> g_sync{0};                                // "sync": block after every launch like the reference
+
+// Which register order each permuted filter buffer was last written in (tfft_conv_filter_layout), newest last.
+struct ConvLayoutTag {
+  int device;
+  const void* ptr;
+  int layout_id;
+};
+std::vector<ConvLayoutTag> g_conv_tags;
+constexpr size_t kMaxConvTags = 256;
+
+std::map<int, float4*> g_static_scratch_addr;  // device -> address of that device's copy of g_static_scratch
 
 constexpr int kMaxLdsN = 16384;       // longest transform one workgroup holds
 constexpr int kMaxBigLog2 = 30;       // longest multi-pass transform
@@ -123,6 +150,7 @@ void free_big(BigPlan& p) {
     if (p.lo[i]) (void)hipFree(p.lo[i]);
   }
   if (p.work) (void)hipFree(p.work);
+  if (p.done) (void)hipEventDestroy(p.done);
   p = BigPlan();
 }
 
@@ -140,11 +168,6 @@ bool lookup(int dtype, int n, bool forward, int mode, tfft::KernelEntry* e) {
   }
 }
 
-Options options_snapshot() {
-  std::lock_guard<std::mutex> lock(g_mu);
-  return g_opt;
-}
-
 const char* dtype_name(int dtype) {
   switch (dtype) {
     case TFFT_F32: return "fp32";
@@ -152,6 +175,50 @@ const char* dtype_name(int dtype) {
     case TFFT_BF16: return "bf16";
     default: return "unknown";
   }
+}
+
+// Address of the current device's copy of the static scratch; resolved on first use per device, which
+// tfft_initialize does for every multi-pass length. g_mu must be held.
+int static_scratch_for(int dev, float4** out) {
+  auto it = g_static_scratch_addr.find(dev);
+  if (it == g_static_scratch_addr.end()) {
+    void* addr = nullptr;
+    TFFT_HIP(hipGetSymbolAddress(&addr, HIP_SYMBOL(g_static_scratch)));
+    if (!addr) return fail(TFFT_ERR_HIP, "hipGetSymbolAddress(static scratch) returned a null address on device %d", dev);
+    it = g_static_scratch_addr.emplace(dev, static_cast<float4*>(addr)).first;
+  }
+  *out = it->second;
+  return TFFT_OK;
+}
+
+// Validates a caller's options. Kernel ids 1 and 2 of the lookup tables are the measurement builds with work
+// compiled out; they are reachable through tfft_bench_access_pattern only, never as a plan.
+int parse_options(const char* who, const tfft_exec_options* in, ExecOpts* out) {
+  *out = ExecOpts();
+  if (!in) return TFFT_OK;
+  if (in->struct_size < (int)offsetof(tfft_exec_options, workspace) || in->struct_size > (int)sizeof(tfft_exec_options))
+    return fail(TFFT_ERR_INVALID, "%s: options struct_size %d (expected %d; use tfft_exec_options_init)", who,
+                in->struct_size, (int)sizeof(tfft_exec_options));
+  if (in->plan < 0 || in->plan == 1 || in->plan == 2)
+    return fail(TFFT_ERR_INVALID, "%s: plan %d is not a transform kernel (0 or >= 3)", who, in->plan);
+  if (in->grid_blocks_per_cu < 0 || in->grid_blocks < 0 || in->extra_lds < 0 || in->extra_lds > 160 * 1024)
+    return fail(TFFT_ERR_INVALID, "%s: negative grid size or extra_lds outside [0, 160 KiB]", who);
+  out->plan = in->plan;
+  out->xcd_run_log2 = in->xcd_run_log2 > 20 ? 20 : in->xcd_run_log2;
+  out->grid_blocks_per_cu = in->grid_blocks_per_cu;
+  out->grid_blocks = in->grid_blocks;
+  out->extra_lds = in->extra_lds;
+  if (in->struct_size >= (int)sizeof(tfft_exec_options)) {
+    out->workspace = in->workspace;
+    out->workspace_bytes = in->workspace_bytes;
+  }
+  return TFFT_OK;
+}
+
+int finish_launch(hipStream_t s) {
+  TFFT_HIP(hipGetLastError());
+  if (g_sync.load(std::memory_order_relaxed)) TFFT_HIP(hipStreamSynchronize(s));
+  return TFFT_OK;
 }
 
 }  // namespace
@@ -174,6 +241,13 @@ int tfft_fourstep_twiddle(int dtype, void* d_data, long long rows, long long col
 }
 
 const char* tfft_last_error(void) { return g_err.c_str(); }
+
+void tfft_exec_options_init(tfft_exec_options* opt) {
+  if (!opt) return;
+  memset(opt, 0, sizeof *opt);
+  opt->struct_size = (int)sizeof *opt;
+  opt->xcd_run_log2 = -1;
+}
 
 int tfft_is_supported(int dtype, int n, int forward) {
   tfft::KernelEntry e;
@@ -211,9 +285,16 @@ static int initialize_big(int n) {
   // transforms go through in few launches
   p.work_batch = std::max<long long>(1, (1LL << 26) / n);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p.work), sizeof(float2) * (size_t)n * (size_t)p.work_batch);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming);
   if (e != hipSuccess) {
     free_big(p);
     return fail(TFFT_ERR_HIP, "tfft_initialize(n=%d): %s", n, hipGetErrorString(e));
+  }
+  // the no-allocation entry point finds this device's copy of its static scratch already resolved
+  float4* unused = nullptr;
+  if (int rc = static_scratch_for(dev, &unused)) {
+    free_big(p);
+    return rc;
   }
   g_big[key] = p;
   return TFFT_OK;
@@ -231,6 +312,12 @@ int tfft_initialize(int dtype, int n) {
   if (g_plans.count(key)) return TFFT_OK;
 
   DevicePlan p;
+  // everything that can fail without owning memory comes first, so that no error path leaks the table
+  hipDeviceProp_t prop;
+  TFFT_HIP(hipGetDeviceProperties(&prop, dev));
+  p.cu_count = prop.multiProcessorCount;
+  TFFT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.blocks_per_cu[0], fwd.fn, fwd.threads, 0));
+  TFFT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.blocks_per_cu[1], inv.fn, inv.threads, 0));
   // 16-bit storage, n >= 256: the table is followed by the lane-ordered tables of the matrix-core kernels
   // (n = 8192, 16384 run 4096-point passes inside: the tables of n = 4096)
   const bool mfma_tables = dtype != TFFT_F32 && n >= 256;
@@ -252,11 +339,6 @@ int tfft_initialize(int dtype, int n) {
     (void)hipFree(p.tw);
     return fail(TFFT_ERR_HIP, "hipMemcpy(twiddle): %s", hipGetErrorString(e));
   }
-  hipDeviceProp_t prop;
-  TFFT_HIP(hipGetDeviceProperties(&prop, dev));
-  p.cu_count = prop.multiProcessorCount;
-  TFFT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.blocks_per_cu[0], fwd.fn, fwd.threads, 0));
-  TFFT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.blocks_per_cu[1], inv.fn, inv.threads, 0));
   g_plans[key] = p;
   return TFFT_OK;
 }
@@ -338,35 +420,40 @@ int tfft_get_twiddle_table(int dtype, int n, const void** d_table) {
 
 int tfft_set_option(const char* key, long long value) {
   if (!key) return fail(TFFT_ERR_INVALID, "tfft_set_option: null key");
-  std::lock_guard<std::mutex> lock(g_mu);
-  if (!strcmp(key, "grid_blocks_per_cu")) g_opt.grid_blocks_per_cu = value;
-  else if (!strcmp(key, "mode")) g_opt.mode = value;
-  else if (!strcmp(key, "sync")) g_opt.sync = value;
-  else if (!strcmp(key, "extra_lds")) g_opt.extra_lds = value;
-  else if (!strcmp(key, "xcd_run_log2")) g_opt.xcd_run_log2 = value > 20 ? 20 : value;
-  else if (!strcmp(key, "grid_blocks")) g_opt.grid_blocks = value;
-  else if (!strcmp(key, "conv_resident_per_cu")) tfft::set_conv_mfma_resident_per_cu((int)value);
-  else return fail(TFFT_ERR_INVALID, "tfft_set_option: unknown key '%s'", key);
+  if (!strcmp(key, "sync")) {
+    g_sync.store(value != 0, std::memory_order_relaxed);
+    return TFFT_OK;
+  }
+  return fail(TFFT_ERR_INVALID, "tfft_set_option: unknown key '%s' (kernel and launch choices are per call: tfft_exec_options)", key);
+}
+
+int tfft_workspace_bytes(int dtype, int n, long long batch, unsigned long long* min_bytes,
+                         unsigned long long* best_bytes) {
+  if (batch < 0) return fail(TFFT_ERR_INVALID, "tfft_workspace_bytes: negative batch");
+  unsigned long long lo = 0, best = 0;
+  if (dtype == TFFT_F32 && n > kMaxLdsN) {
+    int nf, f[3];
+    if (!factor_big(ilog2(n), &nf, f))
+      return fail(TFFT_ERR_UNSUPPORTED, "tfft_workspace_bytes: no multi-pass plan for n=%d", n);
+    lo = sizeof(float2) * (unsigned long long)n;
+    const long long group = std::min<long long>(std::max<long long>(batch, 1), std::max<long long>(1, (1LL << 26) / n));
+    best = lo * (unsigned long long)group;
+  } else {
+    tfft::KernelEntry e;
+    if (!lookup(dtype, n, true, 0, &e))
+      return fail(TFFT_ERR_UNSUPPORTED, "tfft_workspace_bytes: no kernel for %s n=%d", dtype_name(dtype), n);
+  }
+  if (min_bytes) *min_bytes = lo;
+  if (best_bytes) *best_bytes = best;
   return TFFT_OK;
 }
 
-// One large transform per batch entry: 2 or 3 sweeps of tile kernels through the plan's scratch.
-static int exec_big(int n, int forward, const void* d_in, void* d_out, long long batch, hipStream_t s) {
-  int dev = 0;
-  TFFT_HIP(hipGetDevice(&dev));
-  BigPlan p;
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_big.find(std::make_tuple(dev, n));
-    if (it == g_big.end())
-      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
-    p = it->second;
-  }
-  const bool fwd = forward != 0;
-  const long long xcd_opt = options_snapshot().xcd_run_log2;
+// The sweeps of `batch` large transforms through `scratch`, which holds `scratch_batch` transforms of n points.
+static int enqueue_big(const BigPlan& p, int n, bool fwd, const void* d_in, void* d_out, long long batch,
+                       float4* scratch, long long scratch_batch, int xcd_opt, hipStream_t s) {
   constexpr int kSweep = tfft::kTileInCol | tfft::kTileOutCol | tfft::kTileTwiddle;
-  for (long long b = 0; b < batch; b += p.work_batch) {
-    const long long group = std::min<long long>(p.work_batch, batch - b);  // transforms per launch
+  for (long long b = 0; b < batch; b += scratch_batch) {
+    const long long group = std::min<long long>(scratch_batch, batch - b);  // transforms per launch
     const float4* src = static_cast<const float4*>(d_in) + b * (long long)(n / 2);
     float4* dst = static_cast<float4*>(d_out) + b * (long long)(n / 2);
     long long rest = n;  // points of the transform the current sweep starts: f[i] * ... * f[nf-1]
@@ -377,9 +464,9 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
       if (!tfft::lookup_tile(p.f[i], fwd, last ? tfft::kTileOutCol : kSweep, &t))
         return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c: no tile kernel of length %d", p.f[i]);
       tfft::TileArgs a{};
-      a.xcd_log2 = xcd_opt >= 0 ? (int)xcd_opt : 4;  // measured: +1 ... 1.5 points on the sweeps
-      a.in = (i == 0) ? src : p.work;
-      a.out = last ? dst : p.work;
+      a.xcd_log2 = xcd_opt >= 0 ? xcd_opt : 4;  // measured: +1 ... 1.5 points on the sweeps
+      a.in = (i == 0) ? src : scratch;
+      a.out = last ? dst : scratch;
       a.tw = p.tw_f[i];
       a.in_bi = a.out_bi = n;
       const long long cols = rest / p.f[i];  // columns of this sweep inside one enclosing transform
@@ -420,44 +507,73 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
   return TFFT_OK;
 }
 
-int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
-                  void* stream) {
-  if (batch < 0) return fail(TFFT_ERR_INVALID, "tfft_exec_c2c: negative batch %lld", batch);
-  if (batch == 0) return TFFT_OK;
-  if (!d_in || !d_out) return fail(TFFT_ERR_INVALID, "tfft_exec_c2c: null device pointer");
-  if ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u)
-    return fail(TFFT_ERR_INVALID, "tfft_exec_c2c: buffers must be 16-byte aligned");
-  if (dtype == TFFT_F32 && n > kMaxLdsN) {
-    const int rc = exec_big(n, forward, d_in, d_out, batch, static_cast<hipStream_t>(stream));
-    if (rc == TFFT_OK && options_snapshot().sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    return rc;
+// One large transform per batch entry: 2 or 3 sweeps of tile kernels through a scratch buffer.
+static int exec_big(int n, int forward, const void* d_in, void* d_out, long long batch, hipStream_t s,
+                    const ExecOpts& opt) {
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  if (opt.workspace) {
+    // caller-owned scratch: the tables are read-only, so nothing of the plan is shared with other calls
+    if (reinterpret_cast<uintptr_t>(opt.workspace) & 15u)
+      return fail(TFFT_ERR_INVALID, "tfft_exec_c2c_opt: workspace must be 16-byte aligned");
+    const unsigned long long per = sizeof(float2) * (unsigned long long)n;
+    if (opt.workspace_bytes < per)
+      return fail(TFFT_ERR_INVALID, "tfft_exec_c2c_opt: workspace of %llu bytes, n=%d needs at least %llu",
+                  opt.workspace_bytes, n, per);
+    BigPlan p;
+    {
+      std::lock_guard<std::mutex> lock(g_mu);
+      auto it = g_big.find(std::make_tuple(dev, n));
+      if (it == g_big.end())
+        return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
+      p = it->second;
+    }
+    return enqueue_big(p, n, forward != 0, d_in, d_out, batch, static_cast<float4*>(opt.workspace),
+                       (long long)(opt.workspace_bytes / per), opt.xcd_run_log2, s);
   }
-  Options opt;
+  // library-owned scratch: enqueue under the lock, behind the previous user of the scratch
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_big.find(std::make_tuple(dev, n));
+  if (it == g_big.end())
+    return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
+  BigPlan& p = it->second;
+  if (p.used && p.last_stream != s) TFFT_HIP(hipStreamWaitEvent(s, p.done, 0));
+  const int rc = enqueue_big(p, n, forward != 0, d_in, d_out, batch, p.work, p.work_batch, opt.xcd_run_log2, s);
+  // recorded even after a failed sweep: whatever was enqueued still uses the scratch
+  TFFT_HIP(hipEventRecord(p.done, s));
+  p.used = true;
+  p.last_stream = s;
+  return rc;
+}
+
+// Shared body of tfft_exec_c2c(_opt) and tfft_bench_access_pattern: `kernel_id` indexes the lookup tables
+// (0 default, 1 and 2 the measurement builds, >= 3 the alternative plans).
+static int exec_small(const char* who, int dtype, int n, int forward, int kernel_id, const void* d_in, void* d_out,
+                      long long batch, hipStream_t s, const ExecOpts& opt) {
   DevicePlan plan;
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    opt = g_opt;
     auto it = g_plans.find(std::make_tuple(dev, dtype, n));
     if (it == g_plans.end()) {
       tfft::KernelEntry probe;
       if (!lookup(dtype, n, forward != 0, 0, &probe))
-        return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c: no kernel for %s n=%d", dtype_name(dtype), n);
-      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(%s, %d) on device %d first",
+        return fail(TFFT_ERR_UNSUPPORTED, "%s: no kernel for %s n=%d", who, dtype_name(dtype), n);
+      return fail(TFFT_ERR_NOT_INITIALIZED, "%s: call tfft_initialize(%s, %d) on device %d first", who,
                   dtype_name(dtype), n, dev);
     }
     plan = it->second;
   }
   tfft::KernelEntry e;
-  if (!lookup(dtype, n, forward != 0, (int)opt.mode, &e))
-    return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c: no kernel for %s n=%d forward=%d mode=%lld",
-                dtype_name(dtype), n, forward, opt.mode);
+  if (!lookup(dtype, n, forward != 0, kernel_id, &e))
+    return fail(TFFT_ERR_UNSUPPORTED, "%s: no kernel for %s n=%d forward=%d plan=%d", who, dtype_name(dtype), n, forward,
+                kernel_id);
 
   // Small batches of N = 512 / 1024 (fp32): the default plans hold 32 points per thread in 64-thread workgroups,
   // which leaves most of the chip idle when there are at most two workgroups per CU; the 16-points-per-thread
   // plans start twice as many waves and finish 10-30 % sooner there (N = 1024 x 1024: 5.0 vs 6.0 us).
-  if (opt.mode == 0 && dtype == TFFT_F32 && (n == 512 || n == 1024) &&
+  if (kernel_id == 0 && dtype == TFFT_F32 && (n == 512 || n == 1024) &&
       (batch + e.tpb - 1) / e.tpb <= 2LL * plan.cu_count) {
     tfft::KernelEntry small;
     if (lookup(dtype, n, forward != 0, 3 /* the alternative plan */, &small)) e = small;
@@ -465,47 +581,138 @@ int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, 
   const long long nchunks = (batch + e.tpb - 1) / e.tpb;
   // Default: one workgroup per chunk. The hardware dispatcher then hands out chunks in address
   // order as workgroups retire, which streams HBM measurably better than a resident grid walking
-  // the batch with a stride; "grid_blocks_per_cu" selects the resident (persistent) form instead.
+  // the batch with a stride; grid_blocks_per_cu selects the resident (persistent) form instead.
   long long grid = nchunks;
   if (e.resident_per_cu > 0) grid = (long long)e.resident_per_cu * plan.cu_count;
   if (opt.grid_blocks_per_cu > 0) grid = opt.grid_blocks_per_cu * plan.cu_count;
   if (opt.grid_blocks > 0) grid = opt.grid_blocks;
   if (grid > nchunks) grid = nchunks;
   if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, (unsigned)opt.extra_lds,
-           opt.xcd_run_log2 >= 0 ? (int)opt.xcd_run_log2
+           opt.xcd_run_log2 >= 0 ? opt.xcd_run_log2
                                  : (d_in == d_out && e.xcd_log2_in_place >= 0 ? e.xcd_log2_in_place : e.xcd_log2), s);
-  TFFT_HIP(hipGetLastError());
-  if (opt.sync) TFFT_HIP(hipStreamSynchronize(s));
+  return finish_launch(s);
+}
+
+static int check_io(const char* who, const void* d_in, void* d_out, long long batch) {
+  if (batch < 0) return fail(TFFT_ERR_INVALID, "%s: negative batch %lld", who, batch);
+  if (batch == 0) return TFFT_OK;
+  if (!d_in || !d_out) return fail(TFFT_ERR_INVALID, "%s: null device pointer", who);
+  if ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u)
+    return fail(TFFT_ERR_INVALID, "%s: buffers must be 16-byte aligned", who);
   return TFFT_OK;
 }
 
-static int conv_common(const char* who, int dtype, int n, int kind, tfft::ConvEntry* e) {
+int tfft_exec_c2c_opt(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch, void* stream,
+                      const tfft_exec_options* options) {
+  ExecOpts opt;
+  if (int rc = parse_options("tfft_exec_c2c_opt", options, &opt)) return rc;
+  if (int rc = check_io("tfft_exec_c2c", d_in, d_out, batch)) return rc;
+  if (batch == 0) return TFFT_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TFFT_F32 && n > kMaxLdsN) {
+    if (opt.plan != 0) return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c_opt: multi-pass lengths have one plan");
+    if (int rc = exec_big(n, forward, d_in, d_out, batch, s, opt)) return rc;
+    return finish_launch(s);
+  }
+  return exec_small("tfft_exec_c2c", dtype, n, forward, opt.plan, d_in, d_out, batch, s, opt);
+}
+
+int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
+                  void* stream) {
+  return tfft_exec_c2c_opt(dtype, n, forward, d_in, d_out, batch, stream, nullptr);
+}
+
+int tfft_exec_c2c_static(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
+                         void* stream) {
+  if (int rc = check_io("tfft_exec_c2c_static", d_in, d_out, batch)) return rc;
+  if (batch == 0) return TFFT_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // one-kernel lengths use no scratch at all: the ordinary path already allocates nothing
+  if (!(dtype == TFFT_F32 && n > kMaxLdsN))
+    return exec_small("tfft_exec_c2c_static", dtype, n, forward, 0, d_in, d_out, batch, s, ExecOpts());
+  if ((long long)n > kStaticScratchPoints)
+    return fail(TFFT_ERR_UNSUPPORTED,
+                "tfft_exec_c2c_static: n=%d exceeds the static scratch of %lld points (2^15 ... 2^20 supported); use "
+                "tfft_exec_c2c or a caller workspace", n, kStaticScratchPoints);
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  BigPlan p;
+  float4* scratch = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_big.find(std::make_tuple(dev, n));
+    if (it == g_big.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c_static: call tfft_initialize(fp32, %d) on device %d first", n, dev);
+    p = it->second;
+    if (int rc = static_scratch_for(dev, &scratch)) return rc;
+  }
+  // Every sweep writes the part of the scratch it later reads, so nothing needs clearing between calls.
+  if (int rc = enqueue_big(p, n, forward != 0, d_in, d_out, batch, scratch, kStaticScratchPoints / n, -1, s)) return rc;
+  return finish_launch(s);
+}
+
+int tfft_bench_access_pattern(int dtype, int n, int forward, int pattern, const void* d_in, void* d_out,
+                              long long batch, void* stream, const tfft_exec_options* options) {
+  ExecOpts opt;
+  if (int rc = parse_options("tfft_bench_access_pattern", options, &opt)) return rc;
+  if (pattern != 1 && pattern != 2)
+    return fail(TFFT_ERR_INVALID, "tfft_bench_access_pattern: pattern %d (1 = loads and stores only, 2 = no LDS exchange)",
+                pattern);
+  if (opt.plan != 0) return fail(TFFT_ERR_INVALID, "tfft_bench_access_pattern: measures the default kernel only");
+  if (int rc = check_io("tfft_bench_access_pattern", d_in, d_out, batch)) return rc;
+  if (batch == 0) return TFFT_OK;
+  return exec_small("tfft_bench_access_pattern", dtype, n, forward, pattern, d_in, d_out, batch,
+                    static_cast<hipStream_t>(stream), opt);
+}
+
+static int conv_common(const char* who, int dtype, int n, int kind, int plan, tfft::ConvEntry* e) {
   if (kind < TFFT_CONV_COMPLEX || kind > TFFT_CONV_REAL_IN_OUT)
     return fail(TFFT_ERR_INVALID, "%s: unknown kind %d", who, kind);
-  if (!tfft::lookup_conv(dtype, n, kind, (int)options_snapshot().mode, e))
-    return fail(TFFT_ERR_UNSUPPORTED, "%s: no fused convolution kernel for %s n=%d kind=%d", who, dtype_name(dtype), n,
-                kind);
+  if (!tfft::lookup_conv(dtype, n, kind, plan, e))
+    return fail(TFFT_ERR_UNSUPPORTED, "%s: no fused convolution kernel for %s n=%d kind=%d plan=%d", who,
+                dtype_name(dtype), n, kind, plan);
   return TFFT_OK;
 }
 
-int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream) {
+int tfft_conv_filter_layout_opt(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream,
+                                const tfft_exec_options* options) {
+  ExecOpts opt;
+  if (int rc = parse_options("tfft_conv_filter_layout", options, &opt)) return rc;
   tfft::ConvEntry e;
-  if (int rc = conv_common("tfft_conv_filter_layout", dtype, n, TFFT_CONV_COMPLEX, &e)) return rc;
+  if (int rc = conv_common("tfft_conv_filter_layout", dtype, n, TFFT_CONV_COMPLEX, opt.plan, &e)) return rc;
   if (D < 0) return fail(TFFT_ERR_INVALID, "tfft_conv_filter_layout: negative D");
   if (D == 0) return TFFT_OK;
   if (!d_h_freq || !d_h_perm || d_h_freq == d_h_perm)
     return fail(TFFT_ERR_INVALID, "tfft_conv_filter_layout: null or aliased device pointers");
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
   e.layout(d_h_freq, d_h_perm, D, static_cast<hipStream_t>(stream));
   TFFT_HIP(hipGetLastError());
+  {
+    // remember the order this buffer now holds, for the check in tfft_conv_exec
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto it = g_conv_tags.begin(); it != g_conv_tags.end(); ++it)
+      if (it->device == dev && it->ptr == d_h_perm) {
+        g_conv_tags.erase(it);
+        break;
+      }
+    if (g_conv_tags.size() >= kMaxConvTags) g_conv_tags.erase(g_conv_tags.begin());
+    g_conv_tags.push_back(ConvLayoutTag{dev, d_h_perm, e.layout_id});
+  }
   return TFFT_OK;
 }
 
-int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,
-                   void* stream) {
+int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream) {
+  return tfft_conv_filter_layout_opt(dtype, n, d_h_freq, d_h_perm, D, stream, nullptr);
+}
+
+int tfft_conv_exec_opt(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,
+                       void* stream, const tfft_exec_options* options) {
+  ExecOpts opt;
+  if (int rc = parse_options("tfft_conv_exec", options, &opt)) return rc;
   tfft::ConvEntry e;
-  if (int rc = conv_common("tfft_conv_exec", dtype, n, kind, &e)) return rc;
+  if (int rc = conv_common("tfft_conv_exec", dtype, n, kind, opt.plan, &e)) return rc;
   if (B < 0 || D < 0) return fail(TFFT_ERR_INVALID, "tfft_conv_exec: negative B or D");
   if (B == 0 || D == 0) return TFFT_OK;
   if ((long long)B * D > 0x7fffffffLL) return fail(TFFT_ERR_INVALID, "tfft_conv_exec: B * D exceeds 2^31 - 1");
@@ -522,11 +729,20 @@ int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_
       return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_exec: call tfft_initialize(%s, %d) on device %d first",
                   dtype_name(dtype), n, dev);
     plan = it->second;
+    // a filter buffer this library permuted for the other kernel's register order would convolve silently wrong
+    for (const ConvLayoutTag& t : g_conv_tags)
+      if (t.device == dev && t.ptr == d_h_perm && t.layout_id != e.layout_id)
+        return fail(TFFT_ERR_INVALID,
+                    "tfft_conv_exec: d_h_perm was written by tfft_conv_filter_layout for the other kernel "
+                    "(plan 0 and plan 3 use different filter orders); permute it again with this call's plan");
   }
-  e.launch(d_x, d_h_perm, d_y, plan.tw, B, D, static_cast<hipStream_t>(stream));
-  TFFT_HIP(hipGetLastError());
-  if (options_snapshot().sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-  return TFFT_OK;
+  e.launch(d_x, d_h_perm, d_y, plan.tw, B, D, (int)opt.grid_blocks_per_cu, static_cast<hipStream_t>(stream));
+  return finish_launch(static_cast<hipStream_t>(stream));
+}
+
+int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,
+                   void* stream) {
+  return tfft_conv_exec_opt(dtype, n, kind, d_x, d_h_perm, d_y, B, D, stream, nullptr);
 }
 
 int tfft_conv_tiles_exec(int dtype, int n, const void* d_in, const void* d_hf, void* d_out, long long input_len,
@@ -553,9 +769,7 @@ int tfft_conv_tiles_exec(int dtype, int n, const void* d_in, const void* d_hf, v
     plan = it->second;
   }
   e.launch(d_in, d_hf, d_out, plan.tw, input_len, output_len, valid, static_cast<hipStream_t>(stream));
-  TFFT_HIP(hipGetLastError());
-  if (options_snapshot().sync) TFFT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-  return TFFT_OK;
+  return finish_launch(static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

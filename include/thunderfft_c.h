@@ -46,7 +46,10 @@ int tfft_finalize(int dtype);
  * reference's trailing cudaStreamSynchronize is left to the caller (the C++ wrapper does it).
  * n is a power of two: 64 ... 16384 run one LDS-resident kernel per launch (all three element
  * types); 2^15 ... 2^30 (fp32) run 2 or 3 strided sweeps through a scratch buffer that
- * tfft_initialize allocated (four-step; the reference has no transform beyond 4096). */
+ * tfft_initialize allocated (four-step; the reference has no transform beyond 4096). That scratch
+ * is one buffer per (device, n): multi-pass calls that share it are ordered on the device by an
+ * event, so calls from several streams or threads stay correct but do not overlap; pass a
+ * workspace of your own (tfft_exec_c2c_opt) for calls that should. */
 int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
                   void* stream);
 
@@ -69,30 +72,83 @@ typedef struct tfft_plan_info {
 } tfft_plan_info;
 int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
 
-/* Tuning and measurement switches (no reference counterpart).
- *   "grid_blocks_per_cu" : resident grid of value * CU count workgroups that walk the batch
- *                          (0 = default: one workgroup per chunk of transforms)
- *   "grid_blocks"        : resident grid of exactly value workgroups (overrides the per-CU form)
- *   "conv_resident_per_cu": workgroups per CU of the fp16 convolution's resident grid (default 0 = one
- *                          workgroup per signal, which measured faster)
- *   "extra_lds"          : bytes of unused dynamic LDS per workgroup, to lower occupancy
- *   "xcd_run_log2"       : -1 = the kernel's default; L >= 0 = every XCD takes runs of 2^L consecutive chunks of the
- *                          batch (0 = chunk order equals launch order); results do not depend on it
- *   "grid_blocks_per_cu" also sizes the grid of kernels that are resident by default (16-bit storage,
- *                          n = 512, 1024, 2048: three workgroups per CU).
- *   "mode"               : 0 = default kernel; 1 = load/store only, 2 = no LDS exchange (both give wrong
- *                          results on purpose; they price the memory pattern and the butterflies);
- *                          3 and up = the alternative kernels of a (dtype, n) kept for A/B timing (another
- *                          factorisation or workgroup size). 16-bit storage at n >= 256 runs on the matrix
- *                          cores by default; there mode 3 (and 4) are the fp32-VALU kernels and 5-12 other
- *                          forms of the matrix-core kernel: 6 = one workgroup per tile with the twiddle
- *                          table, 10 = one workgroup per tile with incrementally built twiddles, 11 =
- *                          resident grid, 12 = mode 10 with one LDS image (n <= 4096); 5, 7 = one LDS image
- *                          (n = 4096); 8 = split bf16 matrix (bf16, n = 4096). A mode a length
- *                          does not have returns TFFT_ERR_UNSUPPORTED. For the convolution entry points
- *                          mode 3 selects the fp32-VALU kernels for fp16 storage.
- *   "sync"               : 1 = synchronise the stream after every launch like the reference */
+/* Per-call launch options (no reference counterpart: the reference fixes its launch shape at compile time,
+ * detail/thunderfft_impl.cuh:14-32). Every combination gives correct results; the fields choose between kernels
+ * and launch shapes kept for A/B timing. Fill with tfft_exec_options_init, change what is needed, pass to a
+ * *_opt entry point; NULL there means the defaults. Nothing here is process-wide state.
+ *   plan               : 0 = the default kernel of (dtype, n); 3 and up = its alternative kernels (another
+ *                        factorisation, workgroup size or LDS exchange form). 16-bit storage at n >= 256 runs on
+ *                        the matrix cores by default; there 3 (and 4) are the fp32-VALU kernels and 5-12 other
+ *                        forms of the matrix-core kernel: 6 = one workgroup per tile with the twiddle table,
+ *                        10 = one workgroup per tile with incrementally built twiddles, 11 = resident grid,
+ *                        12 = plan 10 with one LDS image (n <= 4096); 5, 7 = one LDS image (n = 4096); 8 = split
+ *                        bf16 matrix (bf16, n = 4096). A plan a length does not have returns
+ *                        TFFT_ERR_UNSUPPORTED. For the convolution entry points plan 3 selects the fp32-VALU
+ *                        kernels for fp16 storage.
+ *   xcd_run_log2       : -1 = the kernel's default; L >= 0 = every XCD takes runs of 2^L consecutive chunks of
+ *                        the batch (0 = chunk order equals launch order); results do not depend on it
+ *   grid_blocks_per_cu : resident grid of value * CU count workgroups that walk the batch (0 = default: one
+ *                        workgroup per chunk of transforms, or the resident size of a kernel that is resident
+ *                        by default). For the fp16 convolution: workgroups per CU of its resident grid
+ *                        (0 = one workgroup per signal, which measured faster).
+ *   grid_blocks        : resident grid of exactly value workgroups (overrides the per-CU form)
+ *   extra_lds          : bytes of unused dynamic LDS per workgroup, to lower occupancy
+ *   workspace(+_bytes) : multi-pass lengths (fp32, n > 16384): caller-owned scratch of at least n points
+ *                        (8 n bytes; tfft_workspace_bytes gives the minimum and the size that takes a batch in
+ *                        one round). With it the call touches no library-owned scratch, so calls on different
+ *                        streams with different workspaces run concurrently. NULL = the scratch
+ *                        tfft_initialize allocated, shared per (device, n): calls that use it are ordered one
+ *                        after the other on the device, whatever their streams. */
+typedef struct tfft_exec_options {
+  int struct_size; /* sizeof(tfft_exec_options); set by tfft_exec_options_init */
+  int plan;
+  int xcd_run_log2;
+  int grid_blocks_per_cu;
+  long long grid_blocks;
+  int extra_lds;
+  int reserved;
+  void* workspace;
+  unsigned long long workspace_bytes;
+} tfft_exec_options;
+void tfft_exec_options_init(tfft_exec_options* opt);
+
+/* tfft_exec_c2c with per-call options (opt == NULL: exactly tfft_exec_c2c). */
+int tfft_exec_c2c_opt(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
+                      void* stream, const tfft_exec_options* opt);
+
+/* tfft_exec_c2c for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): same arguments, same results bit for bit, and neither this call nor
+ * anything it launches allocates or frees. It has no counterpart in the reference. Multi-pass lengths
+ * (fp32, n = 2^15 ... 2^20) run their sweeps through a scratch of 2^20 points (8 MiB) that is part of the
+ * library's code object: every GPU the library runs on holds its own copy until the process ends. Longer
+ * transforms return TFFT_ERR_UNSUPPORTED (use tfft_exec_c2c or a workspace of your own); batches of any size
+ * are folded through the scratch 2^20 / n transforms at a time. n <= 16384 (any dtype) needs no scratch and is
+ * forwarded to the ordinary kernels. tfft_initialize(dtype, n) must have run on the device (it builds the
+ * tables). All calls on one GPU share that GPU's scratch: calls that overlap in time on one GPU (different
+ * streams, or threads) race; order them with events. */
+int tfft_exec_c2c_static(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
+                         void* stream);
+
+/* Scratch a multi-pass transform needs: *min_bytes for one transform at a time, *best_bytes to take `batch`
+ * transforms in as few rounds as the library-owned scratch would (both 0 for n <= 16384). Either pointer may
+ * be NULL. No reference counterpart. */
+int tfft_workspace_bytes(int dtype, int n, long long batch, unsigned long long* min_bytes,
+                         unsigned long long* best_bytes);
+
+/* Process-wide switches (no reference counterpart). The only key is
+ *   "sync" : 1 = synchronise the stream after every launch, the reference's behaviour
+ *            (detail/thunderfft_impl_kernel.cuh:29); 0 (default) = asynchronous.
+ * Kernel and launch-shape choices are per call (tfft_exec_options), never process-wide. */
 int tfft_set_option(const char* key, long long value);
+
+/* MEASUREMENT ONLY -- the output is meaningless. Runs the default kernel of (dtype, n) with part of its work
+ * compiled out, to price the rest: pattern 1 = the global loads and stores alone (the rows are read and written
+ * in the transform's access pattern), pattern 2 = loads, butterflies and stores without the LDS exchanges.
+ * fp32, n <= 16384, lengths that have the build. Kept apart from tfft_exec_c2c so that no option can make a
+ * transform call return wrong data. No reference counterpart (its bench prices on-chip time with in-kernel
+ * repeats instead, sample/bench/util/helper.h:130-136). */
+int tfft_bench_access_pattern(int dtype, int n, int forward, int pattern, const void* d_in, void* d_out,
+                              long long batch, void* stream, const tfft_exec_options* opt);
 
 /* Twiddle step between the two halves of a four-step transform that run as separate batched
  * calls (distributed transforms: local FFTs, all-to-all, local FFTs): element (r, c) of the
@@ -124,6 +180,15 @@ int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_
  * tfft_exec_c2c on the zero-padded filters) into the order tfft_conv_exec reads. d_h_perm must not
  * alias d_h_freq. */
 int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream);
+
+/* The two convolution calls with per-call options (opt == NULL: exactly the calls above). The kernels behind
+ * plan 0 and plan 3 read the permuted filters in different orders: the library remembers which order each
+ * d_h_perm buffer was last written in and tfft_conv_exec(_opt) returns TFFT_ERR_INVALID when asked to read a
+ * buffer with the other kernel. */
+int tfft_conv_exec_opt(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,
+                       void* stream, const tfft_exec_options* opt);
+int tfft_conv_filter_layout_opt(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream,
+                                const tfft_exec_options* opt);
 
 /* Overlap-save tiled convolution with transforms of length n: for every tile t,
  *   out[t*valid + j] = IDFT_n( DFT_n(in[t*valid .. t*valid + n)) * hf )[j],   j < valid, t*valid + j < output_len,

@@ -82,6 +82,45 @@ def test_errors_are_reported():
         fft_amd.set_option("no_such_option", 1)
 
 
+def test_no_option_can_select_a_wrong_result_build():
+    """The measurement builds (kernel ids 1 and 2: work compiled out, meaningless output) are not plans: the
+    transform entry point refuses them before it touches a device, the process-wide switch has no such key, and
+    the measurement entry point takes only those two patterns."""
+    import ctypes
+
+    import fft_amd
+    from fft_amd import _lib
+
+    lib = _lib.load()
+    for key in ("mode", "xcd_run_log2", "grid_blocks_per_cu"):
+        with pytest.raises(fft_amd.ThunderFFTError):
+            fft_amd.set_option(key, 1)
+    buf = ctypes.create_string_buffer(64)  # never dereferenced: the options are rejected first
+    ptr = ctypes.addressof(buf) & ~15
+    for plan in (1, 2, -1):
+        opts = fft_amd.exec_options({"plan": plan})
+        assert lib.tfft_exec_c2c_opt(0, 4096, 1, ptr, ptr, 1, None, opts) == 3
+        assert lib.tfft_conv_exec_opt(1, 4096, 0, ptr, ptr, ptr, 1, 1, None, opts) == 3
+    bad = fft_amd.exec_options({"plan": 3})
+    bad.struct_size = 4
+    assert lib.tfft_exec_c2c_opt(0, 4096, 1, ptr, ptr, 1, None, bad) == 3
+    assert lib.tfft_bench_access_pattern(0, 4096, 1, 3, ptr, ptr, 1, None, None) == 3
+    assert lib.tfft_bench_access_pattern(0, 4096, 1, 1, ptr, ptr, 1, None, fft_amd.exec_options({"plan": 3})) == 3
+    with pytest.raises(fft_amd.ThunderFFTError):
+        fft_amd.exec_options({"no_such_field": 1})
+
+
+def test_workspace_bytes():
+    import fft_amd
+
+    assert fft_amd.workspace_bytes("fp32", 4096, 100) == (0, 0)
+    assert fft_amd.workspace_bytes("fp32", 1 << 20, 1) == (8 << 20, 8 << 20)
+    assert fft_amd.workspace_bytes("fp32", 1 << 20, 1000) == (8 << 20, 8 << 26)  # the library's own round: 2^26 points
+    assert fft_amd.workspace_bytes("fp32", 1 << 28, 3) == (8 << 28, 8 << 28)
+    with pytest.raises(fft_amd.ThunderFFTError):
+        fft_amd.workspace_bytes("fp16", 1 << 20, 1)
+
+
 def test_host_wrapper_rejects_cpu_tensors():
     import torch
 

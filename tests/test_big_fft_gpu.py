@@ -34,8 +34,11 @@ def test_big_vs_oracle(oracle_mod, lg, forward):
     assert err <= 3e-6, f"accuracy regressed: n=2^{lg} rel_l2={err:.3e}"
 
 
-@pytest.mark.parametrize("lg", (24, 26, 27))
-def test_very_big_vs_fp64_fft_and_roundtrip(lg):
+@pytest.mark.parametrize("lg", (24, 26, 27, 28))
+def test_very_big_vs_fp64_fft_and_roundtrip(oracle_mod, lg):
+    """Whole transforms at the large-transform configuration's size and beyond (2^26 is that configuration; 2^28
+    is a three-sweep plan with the longest tile lengths). Up to 2^26 the expected spectrum is the fp64 oracle's,
+    computed on the host; beyond, torch's fp64 FFT on the device stands in (the oracle would need minutes)."""
     n = 1 << lg
     g = torch.Generator(device="cuda").manual_seed(lg)
     x = torch.rand(1, n, 2, device="cuda", generator=g) * 2 - 1
@@ -45,15 +48,102 @@ def test_very_big_vs_fp64_fft_and_roundtrip(lg):
     back = torch.empty_like(x)
     fft_amd.ThunderFFT_global(X, back, 1, n, False)
     torch.cuda.synchronize()
-    ref = torch.fft.fft(torch.view_as_complex(x.double().contiguous()), dim=-1)
-    got = torch.view_as_complex(X.double().contiguous())
-    err = (torch.linalg.vector_norm(got - ref) / torch.linalg.vector_norm(ref)).item()
+    if lg <= 26:
+        xh = x.cpu().numpy().astype(np.float64).reshape(n, 2)
+        ref = torch.from_numpy(oracle_mod.fft(xh[:, 0] + 1j * xh[:, 1], True)).to("cuda")
+        del xh
+    else:
+        ref = torch.fft.fft(torch.view_as_complex(x.double().contiguous()), dim=-1)
+    got = torch.view_as_complex(X.double().contiguous()).reshape(-1)
+    err = (torch.linalg.vector_norm(got - ref.reshape(-1)) / torch.linalg.vector_norm(ref)).item()
     assert err <= 1e-5, f"n=2^{lg} rel_l2={err:.3e}"
     rt = (torch.linalg.vector_norm((back / n - x).double()) / torch.linalg.vector_norm(x.double())).item()
     assert rt <= 1e-5, rt
     del ref, got, X, back, x
     fft_amd.ThunderFFTFinalize("fp32")  # releases the scratch of the big plans
     torch.cuda.empty_cache()
+
+
+def test_batch_larger_than_the_scratch_round(oracle_mod):
+    """The library folds batches through a scratch of 2^26 points: 2049 transforms of 2^15 points take two
+    rounds. Every transform equals the one a small call computes; scattered ones are checked against the oracle."""
+    n, batch = 1 << 15, 2049
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    X = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x, X, batch, n, True)
+    idx = [0, 1, 1023, 2047, 2048]
+    small_in = x[idx].contiguous()
+    small = torch.empty_like(small_in)
+    fft_amd.ThunderFFT_global(small_in, small, len(idx), n, True)
+    torch.cuda.synchronize()
+    assert torch.equal(X[idx], small)
+    xs = small_in.cpu().numpy().astype(np.float64)
+    got = small.cpu().numpy().astype(np.float64)
+    assert oracle_mod.rel_l2(got[..., 0] + 1j * got[..., 1], oracle_mod.fft(xs[..., 0] + 1j * xs[..., 1])) <= 3e-6
+    # Parseval for every transform: a round that missed transforms would leave them unwritten
+    ex = (x.double() ** 2).sum(dim=(1, 2))
+    eX = (X.double() ** 2).sum(dim=(1, 2)) / n
+    assert torch.max(torch.abs(eX / ex - 1)).item() < 1e-5
+
+
+def test_two_streams_share_the_library_scratch():
+    """Multi-pass calls on different streams use the same library-owned scratch; the library orders them on the
+    device, so interleaved launches from two streams still give each call's own result."""
+    n, batch = 1 << 16, 8
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xa = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    xb = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    want_a, want_b = torch.empty_like(xa), torch.empty_like(xb)
+    fft_amd.ThunderFFT_global(xa, want_a, batch, n, True)
+    fft_amd.ThunderFFT_global(xb, want_b, batch, n, True)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(10):
+        ya, yb = torch.zeros_like(xa), torch.zeros_like(xb)
+        torch.cuda.synchronize()
+        fft_amd.ThunderFFT_global(xa, ya, batch, n, True, sa)
+        fft_amd.ThunderFFT_global(xb, yb, batch, n, True, sb)
+        fft_amd.ThunderFFT_global(ya, ya, batch, n, False, sa)
+        fft_amd.ThunderFFT_global(xb, yb, batch, n, True, sb)
+        torch.cuda.synchronize()
+        assert torch.equal(yb, want_b)
+        assert (torch.linalg.vector_norm(ya / n - xa) / torch.linalg.vector_norm(xa)).item() < 2e-6
+
+
+def test_caller_workspace(oracle_mod):
+    """tfft_exec_c2c_opt with a caller-owned workspace: same bits as the library-owned scratch, for a workspace of
+    the best size, of the minimum size (one transform per round) and on two streams with a workspace each."""
+    n, batch = 1 << 17, 5
+    lo, best = fft_amd.workspace_bytes("fp32", n, batch)
+    assert lo == 8 * n and best == 8 * n * batch
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    want = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x, want, batch, n, True)
+    torch.cuda.synchronize()
+    for nbytes in (best, lo, lo + 8 * n // 2):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        got = torch.zeros_like(x)
+        fft_amd.ThunderFFT_global(x, got, batch, n, True, options={"workspace": ws})
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), nbytes
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        fft_amd.ThunderFFT_global(x, got, batch, n, True,
+                                  options={"workspace": torch.empty(lo - 16, dtype=torch.uint8, device="cuda")})
+    assert e.value.code == 3
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    w1 = torch.empty(best, dtype=torch.uint8, device="cuda")
+    w2 = torch.empty(best, dtype=torch.uint8, device="cuda")
+    y1, y2 = torch.zeros_like(x), torch.zeros_like(x)
+    for _ in range(5):
+        fft_amd.ThunderFFT_global(x, y1, batch, n, True, s1, options={"workspace": w1})
+        fft_amd.ThunderFFT_global(x, y2, batch, n, True, s2, options={"workspace": w2})
+    torch.cuda.synchronize()
+    assert torch.equal(y1, want) and torch.equal(y2, want)
 
 
 def test_big_in_place_and_tone(oracle_mod):

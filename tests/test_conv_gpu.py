@@ -152,13 +152,34 @@ def test_resident_form_matches_one_shot():
     hp = conv.filter_spectra(h, N)
     for kind in (conv.CONV_REAL_IN_OUT, conv.CONV_REAL_IN):
         a = conv.fft_conv(x, hp, N, kind)
-        try:
-            fft_amd.set_option("conv_resident_per_cu", 2)
-            b = conv.fft_conv(x, hp, N, kind)
-        finally:
-            fft_amd.set_option("conv_resident_per_cu", 0)
+        b = conv.fft_conv(x, hp, N, kind, options={"grid_blocks_per_cu": 2})
         torch.cuda.synchronize()
         assert torch.equal(a, b), kind
+
+
+def test_valu_plan_and_filter_layout_mismatch(oracle_mod):
+    """fp16 storage: plan 3 runs the fp32-VALU kernels, which read the permuted filters in another order than
+    the matrix-core kernels. Same plan for layout and convolution: both kernels agree with the oracle; a buffer
+    permuted for one kernel and handed to the other is rejected instead of convolving wrong."""
+    B, D, K = 2, 3, 7
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.random((B, D, N)).astype(np.float32)).to("cuda").to(torch.float16)
+    taps = np.zeros((D, K, 2), dtype=np.float32)
+    taps[..., 0] = rng.random((D, K)) / N
+    h = torch.from_numpy(taps).to("cuda").to(torch.float16)
+    ref = oracle_mod.circular_conv(x.float().cpu().numpy().astype(np.float64).reshape(B * D, N) + 0j,
+                                   h.float().cpu().numpy().astype(np.float64)[..., 0] + 0j).real * N
+    hp_mfma = conv.filter_spectra(h, N)
+    hp_valu = conv.filter_spectra(h, N, options={"plan": 3})
+    for hp, opts in ((hp_mfma, None), (hp_valu, {"plan": 3})):
+        y = conv.fft_conv(x, hp, N, conv.CONV_REAL_IN_OUT, options=opts)
+        torch.cuda.synchronize()
+        got = y.float().cpu().numpy().astype(np.float64).reshape(B * D, N)
+        assert oracle_mod.rel_l2(got + 0j, ref + 0j) <= 1e-2
+    for hp, opts in ((hp_mfma, {"plan": 3}), (hp_valu, None)):
+        with pytest.raises(fft_amd.ThunderFFTError) as e:
+            conv.fft_conv(x, hp, N, conv.CONV_REAL_IN_OUT, options=opts)
+        assert e.value.code == 3
 
 
 def test_errors():

@@ -35,12 +35,12 @@ def to_host(t):
     return a[..., 0] + 1j * a[..., 1]
 
 
-def run(x, kind, forward=True, inplace=False):
+def run(x, kind, forward=True, inplace=False, options=None):
     n = x.shape[-1]
     d_in = to_device(x, kind)
     d_out = d_in if inplace else torch.full_like(d_in, float("nan"))
     fft_amd.ThunderFFTInitialize(kind, n)
-    fft_amd.ThunderFFT_global(d_in, d_out, x.shape[0], n, forward)
+    fft_amd.ThunderFFT_global(d_in, d_out, x.shape[0], n, forward, options=options)
     torch.cuda.synchronize()
     return to_host(d_out), to_host(to_device(x, kind))
 
@@ -225,24 +225,18 @@ def test_full_size_properties(n, batch):
 @pytest.mark.parametrize("mode", [3, 4])
 @pytest.mark.parametrize("n", ALL_N)
 def test_alternative_plans_vs_oracle(oracle_mod, n, mode):
-    """Modes 3 and 4 select the A/B plans of a length (another factorisation, workgroup size or LDS
+    """Plans 3 and 4 select the A/B kernels of a length (another factorisation, workgroup size or LDS
     exchange form); a small resident grid makes workgroups loop over chunks."""
     batch = 3 * 256 * max(1, 4096 // n) + 5
     x = synth.uniform_complex(batch, n, seed=n + 99)
-    try:
-        fft_amd.set_option("mode", mode)
-        fft_amd.set_option("grid_blocks_per_cu", 1)
-        for forward in (True, False):
-            try:
-                got, stored = run(x, "fp32", forward)
-            except fft_amd.ThunderFFTError:
-                assert mode == 4, "every length has a first alternative plan"
-                pytest.skip(f"no second alternative plan for n={n}")
-            err = oracle_mod.rel_l2(got, oracle_mod.fft(stored, forward))
-            assert err <= 2e-6, f"n={n} forward={forward} rel_l2={err:.3e}"
-    finally:
-        fft_amd.set_option("mode", 0)
-        fft_amd.set_option("grid_blocks_per_cu", 0)
+    for forward in (True, False):
+        try:
+            got, stored = run(x, "fp32", forward, options={"plan": mode, "grid_blocks_per_cu": 1})
+        except fft_amd.ThunderFFTError:
+            assert mode == 4, "every length has a first alternative plan"
+            pytest.skip(f"no second alternative plan for n={n}")
+        err = oracle_mod.rel_l2(got, oracle_mod.fft(stored, forward))
+        assert err <= 2e-6, f"n={n} forward={forward} rel_l2={err:.3e}"
 
 
 @pytest.mark.parametrize("mode", [0, 3, 4, 5, 6, 7, 11, 12])
@@ -256,14 +250,8 @@ def test_fp16_4096_plans_vs_oracle(oracle_mod, mode, forward):
     n = 4096
     batch = 2500 if mode in (7, 11) else 37  # resident grids: several transforms per workgroup, uneven tail
     x = synth.uniform_complex(batch, n, seed=mode) / np.sqrt(n)  # the reference's input scale, sample/bench/main.cu:36
-    try:
-        fft_amd.set_option("mode", mode)
-        if mode == 7:
-            fft_amd.set_option("grid_blocks_per_cu", 2)
-        got, stored = run(x.astype(np.complex64), "fp16", forward)
-    finally:
-        fft_amd.set_option("mode", 0)
-        fft_amd.set_option("grid_blocks_per_cu", 0)
+    got, stored = run(x.astype(np.complex64), "fp16", forward,
+                      options={"plan": mode, "grid_blocks_per_cu": 2 if mode == 7 else 0})
     ref = oracle_mod.fft(stored, forward)
     err = oracle_mod.rel_l2(got, ref)
     print(f"mode={mode} forward={forward} rel_l2={err:.3e}")
@@ -283,11 +271,7 @@ def test_bf16_4096_plans_vs_oracle(oracle_mod, mode, forward):
     n = 4096
     batch = 2500 if mode in (11, 8) else 37
     x = synth.uniform_complex(batch, n, seed=40 + mode)
-    try:
-        fft_amd.set_option("mode", mode)
-        got, stored = run(x, "bf16", forward)
-    finally:
-        fft_amd.set_option("mode", 0)
+    got, stored = run(x, "bf16", forward, options={"plan": mode})
     ref = oracle_mod.fft(stored, forward)
     err = oracle_mod.rel_l2(got, ref)
     print(f"bf16 mode={mode} forward={forward} rel_l2={err:.3e}")
@@ -311,11 +295,7 @@ def test_half_storage_matrix_core_lengths(oracle_mod, n, kind, mode):
         x = (synth.uniform_complex(batch, n, seed=n + batch) * scale).astype(np.complex64)
         for forward in (True, False):
             for inplace in (False, True):
-                try:
-                    fft_amd.set_option("mode", mode)
-                    got, stored = run(x, kind, forward, inplace=inplace)
-                finally:
-                    fft_amd.set_option("mode", 0)
+                got, stored = run(x, kind, forward, inplace=inplace, options={"plan": mode})
                 ref = oracle_mod.fft(stored, forward)
                 err = oracle_mod.rel_l2(got, ref)
                 assert err <= TOL[kind], f"{kind} n={n} mode={mode} batch={batch} forward={forward} rel_l2={err:.3e}"
@@ -336,11 +316,7 @@ def test_half_storage_matrix_core_long_lengths(oracle_mod, n, kind, mode):
         x = (synth.uniform_complex(batch, n, seed=n + batch) * scale).astype(np.complex64)
         for forward in (True, False):
             for inplace in (False, True):
-                try:
-                    fft_amd.set_option("mode", mode)
-                    got, stored = run(x, kind, forward, inplace=inplace)
-                finally:
-                    fft_amd.set_option("mode", 0)
+                got, stored = run(x, kind, forward, inplace=inplace, options={"plan": mode})
                 ref = oracle_mod.fft(stored, forward)
                 err = oracle_mod.rel_l2(got, ref)
                 assert err <= TOL[kind], f"{kind} n={n} mode={mode} batch={batch} forward={forward} rel_l2={err:.3e}"
@@ -375,11 +351,7 @@ def test_resident_grid_matches_one_shot():
     n, batch = 1024, 5000
     x = synth.uniform_complex(batch, n, seed=21)
     a, _ = run(x, "fp32", True)
-    try:
-        fft_amd.set_option("grid_blocks_per_cu", 1)
-        b, _ = run(x, "fp32", True)
-    finally:
-        fft_amd.set_option("grid_blocks_per_cu", 0)
+    b, _ = run(x, "fp32", True, options={"grid_blocks_per_cu": 1})
     assert np.array_equal(a, b)
 
 
@@ -446,17 +418,10 @@ def test_xcd_chunk_order_does_not_change_results(kind, n):
     batch = (1 if n > 16384 else 777) * per_chunk + per_chunk // 2 + 1
     scale = 1.0 / np.sqrt(n) if kind == "fp16" else 1.0
     x = (synth.uniform_complex(batch, n, seed=3) * scale).astype(np.complex64)
-    try:
-        fft_amd.set_option("xcd_run_log2", 0)
-        want, _ = run(x, kind, True)
-        for log2, grid in ((1, 0), (3, 0), (5, 0), (7, 0), (12, 0), (4, 1)):
-            fft_amd.set_option("xcd_run_log2", log2)
-            fft_amd.set_option("grid_blocks_per_cu", grid)
-            got, _ = run(x, kind, True)
-            assert np.array_equal(got, want), (kind, n, log2, grid)
-    finally:
-        fft_amd.set_option("xcd_run_log2", -1)
-        fft_amd.set_option("grid_blocks_per_cu", 0)
+    want, _ = run(x, kind, True, options={"xcd_run_log2": 0})
+    for log2, grid in ((1, 0), (3, 0), (5, 0), (7, 0), (12, 0), (4, 1)):
+        got, _ = run(x, kind, True, options={"xcd_run_log2": log2, "grid_blocks_per_cu": grid})
+        assert np.array_equal(got, want), (kind, n, log2, grid)
 
 
 def test_linearity():
