@@ -1,9 +1,11 @@
 # Builds libthunderfft_hip.so (gfx950 kernels + C ABI), the CPU oracle and the C++ bench harness.
 # Everything is built in-tree; objects go to build/. -fno-slp-vectorize: packed fp32 VALU ops
 # (v_pk_add_f32 / v_pk_fma_f32) issue at half rate on gfx950 and cost extra v_mov to pair registers.
+# -pragma-unroll-threshold: the kernels index register arrays inside `#pragma unroll` loops; the largest bodies
+# (four 4096-point transforms in one kernel) exceed the default budget, stay rolled and land in scratch memory.
 HIPCC      ?= /opt/rocm/bin/hipcc
 ARCH       ?= gfx950
-HIPFLAGS   ?= -O3 -std=c++17 -fPIC -fno-slp-vectorize --offload-arch=$(ARCH) -Wall -Wno-unused-variable -Wno-unused-but-set-variable
+HIPFLAGS   ?= -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -pragma-unroll-threshold=262144 --offload-arch=$(ARCH) -Wall -Wno-unused-variable -Wno-unused-but-set-variable
 CC         ?= gcc
 
 CSRC       := fft_amd/csrc

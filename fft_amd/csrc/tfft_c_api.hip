@@ -322,13 +322,16 @@ int tfft_initialize(int dtype, int n) {
   // (n = 8192, 16384 run 4096-point passes inside: the tables of n = 4096)
   const bool mfma_tables = dtype != TFFT_F32 && n >= 256;
   const bool conv_tables = mfma_tables && n == tfft::Mfma4096::N;
-  const size_t entries = (size_t)n + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (conv_tables ? tfft::ConvMfma4096::TABLE : 0);
+  // fp32, n = 8192 and 16384: the table of the 4096-point transforms these lengths are built from follows W_n
+  const int sub = (dtype == TFFT_F32 && n > 4096) ? 4096 : 0;
+  const size_t entries = (size_t)n + sub + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (conv_tables ? tfft::ConvMfma4096::TABLE : 0);
   std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
     // exact reduction of the angle: j/n is a dyadic rational, evaluated in fp64 and rounded once
     const double a = -2.0 * M_PI * (double)j / (double)n;
     h[j] = make_float2((float)std::cos(a), (float)std::sin(a));
   }
+  for (int j = 0; j < sub; ++j) h[n + j] = h[(size_t)j * (n / sub)];
   if (mfma_tables) tfft::mfma_lane_tables(h.data() + n, n < tfft::Mfma4096::N ? n : tfft::Mfma4096::N);
   if (conv_tables) {
     tfft::conv_mfma4096_tables(h.data() + tfft::ConvMfma4096::OFFSET);
@@ -588,9 +591,12 @@ static int exec_small(const char* who, int dtype, int n, int forward, int kernel
   if (opt.grid_blocks > 0) grid = opt.grid_blocks;
   if (grid > nchunks) grid = nchunks;
   if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
-  e.launch(d_in, d_out, plan.tw, batch, nchunks, (unsigned)grid, (unsigned)opt.extra_lds,
-           opt.xcd_run_log2 >= 0 ? opt.xcd_run_log2
-                                 : (d_in == d_out && e.xcd_log2_in_place >= 0 ? e.xcd_log2_in_place : e.xcd_log2), s);
+  tfft::LaunchShape shape;
+  shape.grid = (unsigned)grid;
+  shape.extra_lds = (unsigned)opt.extra_lds;
+  shape.xcd_log2 = opt.xcd_run_log2 >= 0 ? opt.xcd_run_log2
+                                         : (d_in == d_out && e.xcd_log2_in_place >= 0 ? e.xcd_log2_in_place : e.xcd_log2);
+  e.launch(d_in, d_out, plan.tw, batch, nchunks, shape, s);
   return finish_launch(s);
 }
 
