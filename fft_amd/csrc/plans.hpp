@@ -215,20 +215,21 @@ KernelEntry make_mfma_big_entry() {
   return e;
 }
 
-// N = 4096 R0, fp32: fft_dit_kernel, one workgroup per transform on the 4096-point block transform.
-template <int R0, bool FWD, int MINW>
+// N = 8192, fp32: fft_dit_kernel, one workgroup per transform on the 4096-point block transform.
+template <bool FWD, int MINW>
 void launch_dit(const void* in, void* out, const float2* tw, long long batch, long long nchunks, const LaunchShape& shape,
                 hipStream_t stream) {
   (void)nchunks;
-  fft_dit_kernel<Plan4096Full, R0, FWD, MINW><<<dim3((unsigned)batch), dim3(Plan4096Full::WG), 0, stream>>>(
+  fft_dit_kernel<Plan4096Full, FWD, MINW><<<dim3((unsigned)batch), dim3(Plan4096Full::WG), 0, stream>>>(
       static_cast<const float4*>(in), static_cast<float4*>(out), tw, batch, shape.xcd_log2);
 }
 
-template <int R0, bool FWD, int MINW>
+template <bool FWD, int MINW>
 KernelEntry make_dit_entry() {
+  constexpr int R0 = 2;
   KernelEntry e;
-  e.fn = reinterpret_cast<const void*>(&fft_dit_kernel<Plan4096Full, R0, FWD, MINW>);
-  e.launch = &launch_dit<R0, FWD, MINW>;
+  e.fn = reinterpret_cast<const void*>(&fft_dit_kernel<Plan4096Full, FWD, MINW>);
+  e.launch = &launch_dit<FWD, MINW>;
   e.n = 4096 * R0;
   e.threads = Plan4096Full::WG;
   e.tpb = 1;

@@ -322,8 +322,8 @@ int tfft_initialize(int dtype, int n) {
   // (n = 8192, 16384 run 4096-point passes inside: the tables of n = 4096)
   const bool mfma_tables = dtype != TFFT_F32 && n >= 256;
   const bool conv_tables = mfma_tables && n == tfft::Mfma4096::N;
-  // fp32, n = 8192 and 16384: the table of the 4096-point transforms these lengths are built from follows W_n
-  const int sub = (dtype == TFFT_F32 && n > 4096) ? 4096 : 0;
+  // fp32, n = 8192: the table of the 4096-point transforms this length is built from follows W_n
+  const int sub = (dtype == TFFT_F32 && n == 8192) ? 4096 : 0;
   const size_t entries = (size_t)n + sub + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (conv_tables ? tfft::ConvMfma4096::TABLE : 0);
   std::vector<float2> h(entries);
   for (int j = 0; j < n; ++j) {
