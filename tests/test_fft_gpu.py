@@ -133,14 +133,32 @@ def test_empty_batch_is_a_noop():
     torch.cuda.synchronize()
 
 
-def test_kat_bench_sine():
-    # reference bench input: X[1] = -i sqrt(N)/2, X[N-1] = +i sqrt(N)/2 (sample/bench/main.cu:35-41)
-    for n in (128, 1024, 4096):
-        got, _ = run(synth.bench_sine(4, n), "fp32", True)
-        want = np.zeros((4, n), dtype=np.complex128)
-        want[:, 1] = -0.5j * np.sqrt(n)
-        want[:, n - 1] = 0.5j * np.sqrt(n)
-        assert np.max(np.abs(got - want)) < 2e-5
+@pytest.mark.parametrize("n", ALL_N)
+def test_kat_fp32_every_length(n):
+    """Known answers from the reference's own inputs, every fp32 length, both directions, a batch that leaves a
+    partial workgroup chunk: the bench sine sin(2 pi n / N) / sqrt(N) (sample/bench/main.cu:35-41) has two
+    non-zero bins, -+ i sqrt(N) / 2 forward and +- i sqrt(N) / 2 inverse; a unit impulse at p gives
+    exp(-+ 2 pi i k p / N); a constant gives the DC bin alone."""
+    batch = 2 * max(1, 4096 // n) + 1
+    for forward in (True, False):
+        sign = -1.0 if forward else 1.0
+        got, _ = run(synth.bench_sine(batch, n), "fp32", forward)
+        want = np.zeros((batch, n), dtype=np.complex128)
+        want[:, 1] = sign * 0.5j * np.sqrt(n)
+        want[:, n - 1] = -sign * 0.5j * np.sqrt(n)
+        assert np.max(np.abs(got - want)) < 2e-5, (n, forward)
+        x = np.zeros((batch, n), dtype=np.complex64)
+        pos = [(37 * b + 5) % n for b in range(batch)]
+        for b in range(batch):
+            x[b, pos[b]] = 1.0
+        got, _ = run(x, "fp32", forward)
+        k = np.arange(n)
+        for b in range(batch):
+            assert np.max(np.abs(got[b] - np.exp(sign * 2j * np.pi * k * pos[b] / n))) < 2e-6, (n, forward, b)
+        got, _ = run(np.full((batch, n), 0.25 / n, dtype=np.complex64), "fp32", forward)
+        want = np.zeros((batch, n), dtype=np.complex128)
+        want[:, 0] = 0.25
+        assert np.max(np.abs(got - want)) < 1e-6, (n, forward)
 
 
 @pytest.mark.parametrize("kind", ("fp16", "bf16"))
@@ -198,10 +216,19 @@ def test_kat_convolution_identity():
     assert np.max(np.abs(y[0] - direct)) < 1e-4
 
 
-@pytest.mark.parametrize("n,batch", ((256, 1 << 18), (4096, 1 << 14), (16384, 1 << 12)))
-def test_full_size_properties(n, batch):
-    """Size-independent checks at bench-scale batches (2^26 points): inverse(forward(x)) = N x,
-    Parseval per transform, and a spot check of 8 scattered transforms against torch's fp64 FFT."""
+def _spot_check_vs_oracle(oracle_mod, x, X, n, idx, tol):
+    xs = x[idx].float().cpu().numpy().astype(np.float64)
+    Xs = X[idx].float().cpu().numpy().astype(np.float64)
+    ref = oracle_mod.fft(xs[..., 0] + 1j * xs[..., 1], True)
+    err = max(oracle_mod.rel_l2(Xs[b, :, 0] + 1j * Xs[b, :, 1], ref[b]) for b in range(len(idx)))
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("n", ALL_N[2:])
+def test_full_size_properties(oracle_mod, n):
+    """Size-independent checks at the sweep configuration's full size (2^28 points per launch, N = 256 ... 16384):
+    inverse(forward(x)) = N x, Parseval per transform, and 8 scattered transforms against the fp64 oracle."""
+    batch = (1 << 28) // n
     g = torch.Generator(device="cuda").manual_seed(n)
     x = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
     fft_amd.ThunderFFTInitialize("fp32", n)
@@ -210,16 +237,47 @@ def test_full_size_properties(n, batch):
     y = torch.empty_like(x)
     fft_amd.ThunderFFT_global(X, y, batch, n, False)
     torch.cuda.synchronize()
-    rt = (torch.linalg.vector_norm((y / n - x).double()) / torch.linalg.vector_norm(x.double())).item()
+    y.div_(n).sub_(x)
+    rt = (torch.linalg.vector_norm(y) / torch.linalg.vector_norm(x)).item()
     assert rt < 2e-6, rt
-    ex = (x.double() ** 2).sum(dim=(1, 2))
-    eX = (X.double() ** 2).sum(dim=(1, 2)) / n
+    del y
+    ex = (x * x).sum(dim=(1, 2), dtype=torch.float64)
+    eX = (X * X).sum(dim=(1, 2), dtype=torch.float64) / n
     assert torch.max(torch.abs(eX / ex - 1)).item() < 1e-5
-    idx = torch.tensor([0, 1, batch // 3, batch // 2, batch - 2, batch - 1, 12345 % batch, 777 % batch], device="cuda")
-    ref = torch.fft.fft(torch.view_as_complex(x[idx].double().contiguous()), dim=-1)
-    got = torch.view_as_complex(X[idx].double().contiguous())
-    err = (torch.linalg.vector_norm(got - ref) / torch.linalg.vector_norm(ref)).item()
-    assert err < 1e-5, err
+    idx = [0, 1, batch // 3, batch // 2, batch - 2, batch - 1, 12345 % batch, 777 % batch]
+    _spot_check_vs_oracle(oracle_mod, x, X, n, idx, 2e-6)
+    del x, X
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind", ("fp16", "bf16"))
+def test_full_size_16bit_configuration(oracle_mod, kind):
+    """The 16-bit configuration at full size, N = 4096 x 65536 in place: round trip, Parseval per transform and
+    8 scattered transforms against the fp64 oracle of the stored inputs."""
+    n, batch = 4096, 65536
+    dt = TORCH_DT[kind]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = ((torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1) / n ** 0.5).to(dt)
+    fft_amd.ThunderFFTInitialize(kind, n)
+    X = x.clone()
+    fft_amd.ThunderFFT_global(X, X, batch, n, True)
+    y = X.clone()
+    fft_amd.ThunderFFT_global(y, y, batch, n, False)
+    torch.cuda.synchronize()
+    tol = TOL[kind]
+    xf = x.float()
+    rt = (torch.linalg.vector_norm(y.float() / n - xf) / torch.linalg.vector_norm(xf)).item()
+    assert rt < tol, rt
+    del y
+    ex = (xf * xf).sum(dim=(1, 2), dtype=torch.float64)
+    Xf = X.float()
+    eX = (Xf * Xf).sum(dim=(1, 2), dtype=torch.float64) / n
+    assert torch.max(torch.abs(eX / ex - 1)).item() < 2 * tol
+    del xf, Xf
+    idx = [0, 1, batch // 3, batch // 2, batch - 2, batch - 1, 12345, 777]
+    _spot_check_vs_oracle(oracle_mod, x, X, n, idx, tol)
+    del x, X
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("mode", [3, 4])
