@@ -13,7 +13,7 @@ LIBDIR     := fft_amd/lib
 BUILD      := build
 
 KERNEL_SRCS := $(CSRC)/inst_f32_a.hip $(CSRC)/inst_f32_b.hip $(CSRC)/inst_f32_c.hip \
-               $(CSRC)/inst_f16.hip $(CSRC)/inst_bf16.hip $(CSRC)/inst_tile.hip $(CSRC)/fourstep_twiddle.hip $(CSRC)/fft_conv.hip $(CSRC)/tfft_c_api.hip
+               $(CSRC)/inst_f16.hip $(CSRC)/inst_bf16.hip $(CSRC)/inst_tile.hip $(CSRC)/fourstep_twiddle.hip $(CSRC)/dist_kernels.hip $(CSRC)/fft_conv.hip $(CSRC)/tfft_c_api.hip
 KERNEL_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(KERNEL_SRCS))
 KERNEL_HDRS := $(wildcard $(CSRC)/*.hpp) include/thunderfft_c.h
 

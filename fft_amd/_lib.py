@@ -19,6 +19,8 @@ SYMBOLS = (
     "tfft_get_plan_info",
     "tfft_set_option",
     "tfft_fourstep_twiddle",
+    "tfft_dist_permute",
+    "tfft_dist_radix",
     "tfft_conv_exec",
     "tfft_conv_exec_opt",
     "tfft_conv_filter_layout",
@@ -56,6 +58,21 @@ class ExecOptions(ctypes.Structure):
     ]
 
 
+class DistPermuteArgs(ctypes.Structure):
+    """tfft_dist_permute_args of include/thunderfft_c.h."""
+    _fields_ = [(k, ctypes.c_longlong) for k in ("nb1", "nb2", "ni", "nj", "in_b1", "in_b2", "in_i",
+                                                  "out_b1", "out_b2", "out_j")] + [
+        ("transpose", ctypes.c_int), ("twiddle", ctypes.c_int), ("tw_n", ctypes.c_longlong),
+        ("tw_shift", ctypes.c_int), ("reserved", ctypes.c_int)] + [
+        (k, ctypes.c_longlong) for k in ("tw_p0", "tw_pi", "tw_q0", "tw_qb1", "tw_qb2", "tw_qj")]
+
+
+class DistRadixArgs(ctypes.Structure):
+    """tfft_dist_radix_args of include/thunderfft_c.h."""
+    _fields_ = [("parts", ctypes.c_int), ("reserved", ctypes.c_int)] + [
+        (k, ctypes.c_longlong) for k in ("rows", "row_len", "in_chunk", "in_pitch", "out_chunk", "out_pitch")]
+
+
 _lib = None
 
 
@@ -91,6 +108,8 @@ def load():
     lib.tfft_get_plan_info.argtypes = [i, i, ctypes.POINTER(PlanInfo)]
     lib.tfft_set_option.argtypes = [cp, ll]
     lib.tfft_fourstep_twiddle.argtypes = [i, vp, ll, ll, ll, ll, ll, i, vp]
+    lib.tfft_dist_permute.argtypes = [vp, vp, ctypes.POINTER(DistPermuteArgs), vp, vp, i, vp]
+    lib.tfft_dist_radix.argtypes = [vp, vp, ctypes.POINTER(DistRadixArgs), vp, i, vp]
     lib.tfft_conv_exec.argtypes = [i, i, i, vp, vp, vp, i, i, vp]
     lib.tfft_conv_filter_layout.argtypes = [i, i, vp, vp, i, vp]
     lib.tfft_conv_tiles_exec.argtypes = [i, i, vp, vp, vp, ll, ll, i, vp]

@@ -223,6 +223,9 @@ int finish_launch(hipStream_t s) {
 
 }  // namespace
 
+// error reporting for the translation units that hold only kernels and their argument checks (dist_kernels.hip)
+extern "C" int tfft_internal_fail(int code, const char* message) { return fail(code, "%s", message); }
+
 extern "C" int tfft_fourstep_twiddle_launch(void* d_data, long long rows, long long cols, long long row0,
                                             long long col0, long long n, int forward, void* stream);
 

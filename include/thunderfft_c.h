@@ -158,6 +158,46 @@ int tfft_bench_access_pattern(int dtype, int n, int forward, int pattern, const 
 int tfft_fourstep_twiddle(int dtype, void* d_data, long long rows, long long cols, long long row0,
                           long long col0, long long n, int forward, void* stream);
 
+/* Local passes of the distributed four-step transform (one large transform over the ranks of a process group:
+ * local transforms, all-to-all exchanges, and between them the two passes below). No counterpart in the
+ * reference, which is single-GPU throughout (sample/fft1d/main.cu:80). fp32 interleaved complex, offsets and
+ * strides in points. Asynchronous on `stream`; nothing is allocated.
+ *
+ * tfft_dist_permute: for b1 < nb1, b2 < nb2, i < ni, j < nj
+ *     transpose = 1:  out[b1 out_b1 + b2 out_b2 + j out_j + i] = w * in[b1 in_b1 + b2 in_b2 + i in_i + j]
+ *     transpose = 0:  out[b1 out_b1 + b2 out_b2 + i out_j + j] = w * in[b1 in_b1 + b2 in_b2 + i in_i + j]
+ * with w = 1, or when twiddle = 1 the four-step factor w = W_n^(p q), W_n = exp(-2 pi i / tw_n) (conjugated when
+ * forward == 0), p = tw_p0 + tw_pi i, q = tw_q0 + tw_qb1 b1 + tw_qb2 b2 + tw_qj j, taken from the two-level table
+ * W_n^e = hi[e >> tw_shift] * lo[e & (2^tw_shift - 1)] (hi: n >> tw_shift entries W_n^(k << tw_shift); lo:
+ * 2^tw_shift entries W_n^k; float2 (cos, -sin), built by the caller). Extents and strides must be even (16-byte
+ * accesses); in and out must not overlap. */
+typedef struct tfft_dist_permute_args {
+  long long nb1, nb2, ni, nj;
+  long long in_b1, in_b2, in_i;
+  long long out_b1, out_b2, out_j;
+  int transpose, twiddle;
+  long long tw_n;
+  int tw_shift, reserved;
+  long long tw_p0, tw_pi, tw_q0, tw_qb1, tw_qb2, tw_qj;
+} tfft_dist_permute_args;
+int tfft_dist_permute(const void* d_in, void* d_out, const tfft_dist_permute_args* args, const void* d_tw_hi,
+                      const void* d_tw_lo, int forward, void* stream);
+
+/* tfft_dist_radix: a rank that holds `parts` chunks of `rows` rows of row_len points (chunk s = the part of every
+ * row that rank s contributed) turns them into `parts` batches of rows whose own row_len-point transforms
+ * complete the (parts * row_len)-point transform of every row:
+ *     out[k out_chunk + r out_pitch + t] = W_M^(t k) * sum_s W_parts^(s k) in[s in_chunk + r in_pitch + t],
+ * k < parts, r < rows, t < row_len, M = parts * row_len, d_table = W_M^e, e < M (float2 (cos, -sin)); conjugated
+ * when forward == 0. parts = 2, 4 or 8; row_len a power of two; strides even. In place (d_in == d_out with equal
+ * strides) is allowed. */
+typedef struct tfft_dist_radix_args {
+  int parts, reserved;
+  long long rows, row_len;
+  long long in_chunk, in_pitch, out_chunk, out_pitch;
+} tfft_dist_radix_args;
+int tfft_dist_radix(const void* d_in, void* d_out, const tfft_dist_radix_args* args, const void* d_table, int forward,
+                    void* stream);
+
 /* Fused circular convolution of length n through the frequency domain, one kernel per call:
  *   y[b][d] = IDFT_n( DFT_n(x[b][d]) * H[d] ),  b < B, d < D,  unnormalised (scale h by 1/n beforehand,
  * as the reference does, sample/conv1d/conv1d_fullfft_l4096_thunder.cu:352-361).

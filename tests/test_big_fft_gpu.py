@@ -173,33 +173,99 @@ def test_big_supported_table():
     assert prod == 1 << 26
 
 
-@pytest.mark.parametrize("lg", (14, 20, 24))
-def test_distributed_plan_single_rank_hip_ops(oracle_mod, lg):
-    """The distributed four-step driver with the HIP local numerics (FFT rows through the C ABI,
-    tfft_fourstep_twiddle) on one rank; the exchange logic itself is covered by the gloo tests."""
-    from fft_amd.distributed import DistributedFFT
+def _to_dev(z):
+    return torch.from_numpy(np.stack([z.real, z.imag], axis=-1).astype(np.float32)).to("cuda")
+
+
+def _to_c(t):
+    a = t.cpu().numpy().astype(np.float64)
+    return a[..., 0] + 1j * a[..., 1]
+
+
+@pytest.mark.parametrize("world,lg", ((1, 14), (1, 24), (2, 14), (4, 16), (8, 18), (8, 22)))
+def test_distributed_virtual_ranks_hip(oracle_mod, world, lg):
+    """The distributed four-step transform with every local pass on the HIP kernels (tfft_dist_permute,
+    tfft_dist_radix, tfft_exec_c2c): all `world` ranks stepped inside this process on the one GPU, the exchanges
+    as chunk copies (run_virtual). Natural and transposed layouts, both directions, against the fp64 oracle."""
+    from fft_amd.distributed import DistributedFFT, HipOps, run_virtual
 
     n = 1 << lg
-    x = synth.uniform_complex(1, n, seed=40 + lg)
-    t = torch.from_numpy(x.view(np.float32).reshape(n, 2)).to("cuda")
-    plan = DistributedFFT(n)
+    x = synth.uniform_complex(1, n, seed=40 + lg)[0]
+    ops = HipOps()
+    plans = [DistributedFFT(n, ops=ops, rank=r, world=world) for r in range(world)]
+    per = n // world
+    shards = [_to_dev(x[r * per:(r + 1) * per]) for r in range(world)]
+    n1, n2, c2 = plans[0].n1, plans[0].n2, plans[0].c2
+    cols = [_to_dev(np.ascontiguousarray(x.reshape(n1, n2)[:, r * c2:(r + 1) * c2].T)) for r in range(world)]
     for forward in (True, False):
-        nat = plan.transform(t.clone(), forward)
-        torch.cuda.synchronize()
-        a = nat.cpu().numpy().astype(np.float64).reshape(n, 2)
-        got = a[:, 0] + 1j * a[:, 1]
         if lg <= 20:
-            ref = oracle_mod.fft(x[0], forward)
+            ref = oracle_mod.fft(x, forward)
         else:
-            xc = torch.view_as_complex(t.double().contiguous())
+            xc = torch.from_numpy(x.astype(np.complex128)).to("cuda")
             ref = (torch.fft.fft(xc) if forward else torch.fft.ifft(xc) * n).cpu().numpy()
-        err = oracle_mod.rel_l2(got, ref)
-        assert err <= 1e-5, f"n=2^{lg} forward={forward} rel_l2={err:.3e}"
-        z = plan.transform(t.clone(), forward, output_layout="transposed")
+        res = run_virtual(plans, shards, forward)
         torch.cuda.synchronize()
-        b = z.cpu().numpy().astype(np.float64)
-        gz = b[..., 0] + 1j * b[..., 1]
-        assert oracle_mod.rel_l2(gz, np.asarray(ref).reshape(plan.n2, plan.n1).T) <= 1e-5
+        nat = np.concatenate([_to_c(t).reshape(-1) for t in res])
+        err = oracle_mod.rel_l2(nat, ref)
+        assert err <= 1e-5, f"n=2^{lg} world={world} forward={forward} rel_l2={err:.3e}"
+        assert err <= 2e-6, err
+        assert plans[0].passes == (8 if world > 1 else 5)
+        for r in range(world):
+            assert torch.equal(shards[r], _to_dev(x[r * per:(r + 1) * per]))  # inputs untouched
+        res = run_virtual(plans, cols, forward, input_layout="transposed", output_layout="transposed")
+        torch.cuda.synchronize()
+        assert plans[0].passes == (5 if world > 1 else 4)
+        for r in range(world):
+            err = oracle_mod.rel_l2(_to_c(res[r]), ref[plans[r].transposed_output_index()])
+            assert err <= 2e-6, (r, err)
+
+
+def test_dist_pass_kernels_match_their_definition():
+    """tfft_dist_permute and tfft_dist_radix against the fp64 evaluation of their definitions (NumpyOps) on
+    shapes that are not multiples of the 64 x 64 tile, with batch strides, with and without the twiddle, both
+    directions, in place for the radix pass."""
+    from fft_amd.distributed import HipOps, NumpyOps, permute_spec, radix_spec
+
+    hip, ref = HipOps(), NumpyOps()
+    rng = np.random.default_rng(3)
+    n_tw = 1 << 20
+    hip.prepare(set(), {2 * 128, 4 * 128, 8 * 64}, {n_tw})
+    specs = [
+        permute_spec(nb1=3, nb2=2, ni=70, nj=46, in_b1=46, in_b2=3 * 46 * 80, in_i=3 * 46 + 2, out_b1=2 * 46 * 72,
+                     out_b2=46 * 72, out_j=72),
+        permute_spec(nb1=2, nb2=3, ni=64, nj=130, in_b1=3 * 64 * 130, in_b2=64 * 130, in_i=130, out_b1=3 * 130 * 64,
+                     out_b2=130 * 64, out_j=64,
+                     twiddle=dict(n=n_tw, p0=12345, pi=3, q0=7, qb1=1001, qb2=17, qj=5)),
+        permute_spec(nb1=4, nb2=1, ni=33, nj=200, in_b1=33 * 200, in_i=200, out_b1=200, out_j=4 * 200, transpose=0),
+        permute_spec(nb1=2, nb2=1, ni=10, nj=64, in_b1=640, in_i=64, out_b1=640, out_j=64, transpose=0,
+                     twiddle=dict(n=n_tw, p0=1, pi=1, q0=0, qb1=64, qb2=0, qj=1)),
+    ]
+    for spec in specs:
+        points = 1 << 16
+        z = rng.standard_normal(points) + 1j * rng.standard_normal(points)
+        for forward in (True, False):
+            src_h, dst_h = _to_dev(z), torch.zeros(points, 2, device="cuda")
+            src_r = torch.from_numpy(np.stack([z.real, z.imag], axis=-1))
+            dst_r = ref.empty(points)
+            hip.permute(src_h, dst_h, spec, forward)
+            ref.permute(src_r, dst_r, spec, forward)
+            torch.cuda.synchronize()
+            got, want = _to_c(dst_h), dst_r.numpy()[:, 0] + 1j * dst_r.numpy()[:, 1]
+            assert np.max(np.abs(got - want)) < 2e-6 * max(1.0, np.max(np.abs(want))), spec
+    for parts, rows, row_len, pitch in ((2, 5, 128, 130), (4, 3, 128, 128), (8, 7, 64, 64)):
+        chunk = rows * pitch + 6
+        points = parts * chunk
+        z = rng.standard_normal(points) + 1j * rng.standard_normal(points)
+        spec = radix_spec(parts, rows, row_len, chunk, pitch, chunk, pitch)
+        for forward in (True, False):
+            buf_h = _to_dev(z)
+            hip.radix(buf_h, buf_h, spec, forward)  # in place
+            src_r = torch.from_numpy(np.stack([z.real, z.imag], axis=-1))
+            out_r = src_r.clone()  # the gaps between rows keep their input values, as in place on the device
+            ref.radix(src_r, out_r, spec, forward)
+            torch.cuda.synchronize()
+            got, want = _to_c(buf_h), out_r.numpy()[:, 0] + 1j * out_r.numpy()[:, 1]
+            assert np.max(np.abs(got - want)) < 4e-6 * np.max(np.abs(want)), (parts, forward)
 
 
 def test_fourstep_twiddle_kernel(oracle_mod):
