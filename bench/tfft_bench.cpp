@@ -372,6 +372,19 @@ void run_one(const Args& a, int n) {
       const float t_2r = time_ms(s, 1, 1, [&] { launch_benchmark_reg_n(n, buf, batch, 2 * R, s); });
       compute_ms = ((double)t_2r - (double)t_r) / (double)R;
     }
+  } else {
+    // 16-bit storage: the matrix-core kernels run their passes R and 2R times per tile on chip (the reference
+    // times its half-precision kernels the same way, sample/bench/main.cu:52-57); one pass here is registers ->
+    // three matrix-core passes -> natural-order LDS image -> registers, the counterpart of its _smem variant
+    if (a.inside_repeats > 0 && n >= 256 && n <= 4096) {
+      const int R = a.inside_repeats;
+      const int dt = thunderfft::dtype_code<T>();
+      const float t_r = time_ms(s, 1, 1, [&] {
+        thunderfft::check(tfft_bench_onchip_repeats(dt, n, R, d_perf, d_perf, batch, s), "onchip repeats"); });
+      const float t_2r = time_ms(s, 1, 1, [&] {
+        thunderfft::check(tfft_bench_onchip_repeats(dt, n, 2 * R, d_perf, d_perf, batch, s), "onchip repeats"); });
+      compute_ms = ((double)t_2r - (double)t_r) / (double)R;
+    }
   }
 
   const double bpp = 2.0 * sizeof(vec2_t<T>);

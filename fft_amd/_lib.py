@@ -15,6 +15,7 @@ SYMBOLS = (
     "tfft_exec_options_init",
     "tfft_workspace_bytes",
     "tfft_bench_access_pattern",
+    "tfft_bench_onchip_repeats",
     "tfft_is_supported",
     "tfft_get_plan_info",
     "tfft_set_option",
@@ -102,6 +103,7 @@ def load():
     lib.tfft_exec_options_init.restype = None
     lib.tfft_workspace_bytes.argtypes = [i, i, ll, ullp, ullp]
     lib.tfft_bench_access_pattern.argtypes = [i, i, i, i, vp, vp, ll, vp, op]
+    lib.tfft_bench_onchip_repeats.argtypes = [i, i, i, vp, vp, ll, vp]
     lib.tfft_conv_exec_opt.argtypes = [i, i, i, vp, vp, vp, i, i, vp, op]
     lib.tfft_conv_filter_layout_opt.argtypes = [i, i, vp, vp, i, vp, op]
     lib.tfft_is_supported.argtypes = [i, i, i]

@@ -323,10 +323,15 @@ constexpr int mfma_out_words() {
 // R1 = N / 256; a tile is 4096 points = 16 / R1 transforms, `batch` counts transforms.
 // INCR: the pass-1 twiddles W^(k1 c) of the four columns c0 .. c0 + 3 of a lane are built from W^(k1 c0)
 // and the step W^k1 (32 + 32 bytes of tables per lane instead of 128; 12 more complex multiplications per tile).
-template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false>
+// REPEAT (measurement builds only): the three passes run `repeats` times on the tile, the natural-order output
+// image of one round being read back as the rows of the next, so that the launch prices the on-chip work
+// (registers -> three passes -> LDS image -> registers) without more HBM traffic. Values overflow; timing only.
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false,
+          bool REPEAT = false>
 __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* in, u32x4_t* out,  // in and out may alias (in-place calls)
                                                                      const float2* __restrict__ tw, long long batch,
-                                                                     int xcd_log2) {
+                                                                     int xcd_log2, unsigned repeats = 1) {
+  static_assert(!REPEAT || !PERSIST, "the repeat build is a one-shot kernel");
   static_assert(R1 == 1 || R1 == 2 || R1 == 4 || R1 == 8 || R1 == 16, "N = 256 R1");
   static_assert(!INCR || R1 > 1, "N = 256 has no first pass");
   constexpr int OUT_WORDS = mfma_out_words<R1>();
@@ -394,6 +399,10 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     return make_float2(re * t.x + im * t.y, im * t.x - re * t.y);
   };
   for (;;) {
+  const long long next = tr + gridDim.x;
+  const long long next_tile = xcd_chunk(next, tiles, xcd_log2);
+  unsigned round = 0;
+  for (;;) {  // one trip, or `repeats` trips in the measurement build
   // ---- pass 1: transpose rows <-> lane groups, then 16 columns {64w + 4i + j} per j
   u32x4_t packed[4];
 #pragma unroll
@@ -409,8 +418,6 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     a2 = s[0]; a3 = s[1];
     packed[j] = u32x4_t{a0, a1, a2, a3};  // rows 4g .. 4g+3 of column 64w + 4i + j
   }
-  const long long next = tr + gridDim.x;
-  const long long next_tile = xcd_chunk(next, tiles, xcd_log2);
   if (PERSIST && next < tiles) request_rows(next_tile);
   c32 run[4];
   if constexpr (INCR) {
@@ -501,6 +508,13 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
       *reinterpret_cast<u32x4_t*>(&img_a[slot0 + R_STEP * r]) = u32x4_t{last[r][0], last[r][1], last[r][2], last[r][3]};
   }
   __syncthreads();
+  if (!REPEAT || ++round >= repeats) break;
+  // next round: this lane's rows 4G + g, columns 64w + 4i .. 4i + 3, back from the natural-order image
+#pragma unroll
+  for (int G = 0; G < 4; ++G)
+    rows[G] = *reinterpret_cast<const u32x4_t*>(&img_a[mfma_out_slot<R1>(4 * ((4 * G + g) * 64 + 16 * w + i))]);
+  __syncthreads();
+  }
 
   // ---- natural order out, 16 bytes per lane
   const int last_cur = last_row(tile);

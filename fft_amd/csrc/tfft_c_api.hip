@@ -675,6 +675,31 @@ int tfft_bench_access_pattern(int dtype, int n, int forward, int pattern, const 
                     static_cast<hipStream_t>(stream), opt);
 }
 
+int tfft_bench_onchip_repeats(int dtype, int n, int repeats, const void* d_in, void* d_out, long long batch,
+                              void* stream) {
+  if (int rc = check_io("tfft_bench_onchip_repeats", d_in, d_out, batch)) return rc;
+  if (repeats < 1 || repeats > (1 << 20)) return fail(TFFT_ERR_INVALID, "tfft_bench_onchip_repeats: repeats in [1, 2^20]");
+  if (batch == 0) return TFFT_OK;
+  if (dtype != TFFT_F16 && dtype != TFFT_BF16)
+    return fail(TFFT_ERR_UNSUPPORTED, "tfft_bench_onchip_repeats: the 16-bit matrix-core kernels only");
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  DevicePlan plan;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+    if (it == g_plans.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_bench_onchip_repeats: call tfft_initialize(%s, %d) on device %d first",
+                  dtype_name(dtype), n, dev);
+    plan = it->second;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool ok = dtype == TFFT_F16 ? tfft::launch_repeat_f16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, s)
+                                    : tfft::launch_repeat_bf16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, s);
+  if (!ok) return fail(TFFT_ERR_UNSUPPORTED, "tfft_bench_onchip_repeats: n = 256 ... 4096");
+  return finish_launch(s);
+}
+
 static int conv_common(const char* who, int dtype, int n, int kind, int plan, tfft::ConvEntry* e) {
   if (kind < TFFT_CONV_COMPLEX || kind > TFFT_CONV_REAL_IN_OUT)
     return fail(TFFT_ERR_INVALID, "%s: unknown kind %d", who, kind);

@@ -158,6 +158,14 @@ int tfft_bench_access_pattern(int dtype, int n, int forward, int pattern, const 
 int tfft_fourstep_twiddle(int dtype, void* d_data, long long rows, long long cols, long long row0,
                           long long col0, long long n, int forward, void* stream);
 
+/* MEASUREMENT ONLY -- the output is meaningless (values overflow). The default matrix-core kernel of a 16-bit
+ * length (fp16 / bf16, n = 256 ... 4096) with its three passes run `repeats` times per tile on chip (registers ->
+ * passes -> natural-order LDS image -> registers) between one load and one store of the tile. Two launches with R
+ * and 2R repeats give the on-chip time per pass, (t(2R) - t(R)) / R: the reference's compute_ms protocol for its
+ * half-precision kernels (sample/bench/main.cu:52-57, baseline/thunderfft_bench.h:139-182, util/helper.h:130-136). */
+int tfft_bench_onchip_repeats(int dtype, int n, int repeats, const void* d_in, void* d_out, long long batch,
+                              void* stream);
+
 /* Local passes of the distributed four-step transform (one large transform over the ranks of a process group:
  * local transforms, all-to-all exchanges, and between them the two passes below). No counterpart in the
  * reference, which is single-GPU throughout (sample/fft1d/main.cu:80). fp32 interleaved complex, offsets and
