@@ -143,6 +143,8 @@ def kernel_label(dtype, n, radix):
         if n > 16384:
             return (f"tfft::fft_tile_kernel x {len(radix)} sweeps ({'x'.join(map(str, radix))}), forward: "
                     "strided column sweeps with four-step twiddles, last sweep writes natural order")
+        if n == 8192:
+            return "tfft::fft_dit_kernel<Plan4096, forward> (two interleaved 4096-point transforms per workgroup)"
         return f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>"
     if 256 <= n <= 4096:
         return f"tfft::fft_mfma4096_kernel<{dtype}, forward, N={n}>"

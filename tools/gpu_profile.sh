@@ -3,7 +3,8 @@
 # counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass). Outputs land in gpurun_out/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/${PROF_DIR:-prof}
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp

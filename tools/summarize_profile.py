@@ -7,7 +7,11 @@
 HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (both counters are in KiB): on gfx950
 FETCH_SIZE tallies the 128-byte requests of a wide coalesced stream at 64 bytes, WRITE_SIZE is exact.
 
-Usage: python tools/summarize_profile.py <tag> [n] [batch] [dtype]     (dtype fp32 | fp16 | bf16, default fp32)
+Usage: python tools/summarize_profile.py <tag> [n] [batch] [dtype] [dir]   (dtype fp32 | fp16 | bf16, default fp32;
+       dir = the run's directory under gpurun_out/, default prof)
+
+The FFT kernel of a run is the library kernel (tfft::...) with the largest total duration; multi-pass lengths run
+several (one per sweep): their counters are summed per transform.
 """
 import csv
 import json
@@ -21,9 +25,13 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    if "fft_lds_kernel" in name or "fft_mfma" in name:
+    if "tfft::" in name:
         return name.split("(")[0].replace("void ", "")
     return name.split("<")[0].replace("void ", "")[:80]
+
+
+def is_fft(name):
+    return "tfft::fft_" in name
 
 
 def main():
@@ -31,11 +39,13 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     dtype = sys.argv[4] if len(sys.argv) > 4 else "fp32"
-    # fp32 runs the VALU kernel; 16-bit storage at n >= 256 the matrix-core kernels
-    want = "fft_lds_kernel" if dtype == "fp32" else "fft_mfma"
+    src = os.path.join(ROOT, "gpurun_out", sys.argv[5]) if len(sys.argv) > 5 else SRC
     bytes_per_point = 16 if dtype == "fp32" else 8
     os.makedirs(DST, exist_ok=True)
-    rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.csv"))))
+    fft_rows = sorted((r for r in rows if is_fft(r["Name"])), key=lambda r: -float(r["TotalDurationNs"]))
+    sweeps = len(fft_rows) if n > 16384 else 1  # multi-pass: every sweep is its own kernel instantiation or launch
+    fft_names = {r["Name"] for r in (fft_rows if n > 16384 else fft_rows[:1])}
     with open(os.path.join(DST, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
@@ -44,16 +54,26 @@ def main():
                         r["MaxNs"], r["StdDev"]])
     pmc = {}
     for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(SRC, sub, "bench_counter_collection.csv")))
-                if want in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, sub, "bench_counter_collection.csv")))
+                if r["Kernel_Name"] in fft_names and r["Counter_Name"] == counter]
         pmc[counter] = {"launches": len(vals), "mean_kib": statistics.mean(vals), "min_kib": min(vals), "max_kib": max(vals)}
     hbm = int((2 * pmc["FETCH_SIZE"]["mean_kib"] + pmc["WRITE_SIZE"]["mean_kib"]) * 1024)
-    fft = [r for r in rows if want in r["Name"]][0]
+    fft = fft_rows[0]
+    launches_per_transform = 1
+    if n > 16384:
+        # kernel launches per transform: the mean above is per launch, the record per transform
+        total_calls = sum(int(r["Calls"]) for r in fft_rows)
+        steps = max(1, min(int(r["Calls"]) for r in fft_rows))
+        launches_per_transform = max(1, round(total_calls / steps))
+        hbm *= launches_per_transform
     rec = {
         "kernel": short(fft["Name"]),
         "n": n,
         "batch": batch,
+        "kernel_launches_per_transform": launches_per_transform,
         "avg_launch_ns_under_rocprofv3": float(fft["AverageNs"]),
+        "all_fft_kernels": [{"kernel": short(r["Name"]), "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
+                            for r in fft_rows],
         "counters": pmc,
         "correction": "HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE reads half of a wide coalesced stream on gfx950",
         "hbm_bytes_per_launch": hbm,
