@@ -48,6 +48,8 @@ using vec2_t = typename thunderfft_vec2<T>::type;
       std::exit(EXIT_FAILURE);                                                            \
     }                                                                                     \
   } while (0)
+// The name the reference's samples check runtime calls with (detail/util_cuda.h:10-18): same print-and-exit.
+#define CHECK_CUDA(call) CHECK_HIP(call)
 
 namespace thunderfft {
 

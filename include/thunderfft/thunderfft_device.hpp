@@ -245,3 +245,51 @@ inline const float2* twiddle_table(int N) {
 }
 
 }  // namespace thunderfft
+
+// ---- global-namespace helpers the reference's samples use beside the device API -------------------------------
+// (detail/util_arith.h:16-30, 123-135, 148-167). They describe the reference's own register and shared-memory
+// layouts; here they keep their arithmetic meaning so that sample code that calls them still compiles and computes
+// the same indices.
+
+// Shared-memory padding, in points, behind one N-point transform: the reference sizes its dynamic shared memory as
+// sizeof(vec2) * (N + pad_h(N)) * batch_per_block<N> (detail/thunderfft_impl_kernel.cuh:18). Here the same formula
+// with sizeof(float2) covers the transform's LDS workspace (thunderfft::workspace_bytes<N>), whatever T is.
+constexpr int pad_h(int N) {
+  constexpr auto points = [](int bytes, int n, int bpb) { return (bytes + 8 * bpb - 1) / (8 * bpb) - n; };
+  switch (N) {
+    case 64: return points(thunderfft::workspace_bytes<64>, 64, thunderfft::batch_per_block<64>);
+    case 128: return points(thunderfft::workspace_bytes<128>, 128, thunderfft::batch_per_block<128>);
+    case 256: return points(thunderfft::workspace_bytes<256>, 256, thunderfft::batch_per_block<256>);
+    case 512: return points(thunderfft::workspace_bytes<512>, 512, thunderfft::batch_per_block<512>);
+    case 1024: return points(thunderfft::workspace_bytes<1024>, 1024, thunderfft::batch_per_block<1024>);
+    case 2048: return points(thunderfft::workspace_bytes<2048>, 2048, thunderfft::batch_per_block<2048>);
+    case 4096: return points(thunderfft::workspace_bytes<4096>, 4096, thunderfft::batch_per_block<4096>);
+    case 8192: return points(thunderfft::workspace_bytes<8192>, 8192, thunderfft::batch_per_block<8192>);
+    case 16384: return points(thunderfft::workspace_bytes<16384>, 16384, thunderfft::batch_per_block<16384>);
+    default: return -1;
+  }
+}
+
+// Index x of N bits with its r-bit digits in reverse order (base-2^r digit reversal); the N % r bits above the
+// last whole digit follow, lowest first.
+template <int r, int N>
+__host__ __device__ constexpr int reverse_bit_groups(int x) {
+  constexpr int digits = N / r;
+  int y = 0;
+  for (int d = 0; d < digits; ++d) y |= ((x >> (r * d)) & ((1 << r) - 1)) << (r * (digits - 1 - d));
+  for (int b = r * digits; b < N; ++b) y = (y << 1) | ((x >> b) & 1);
+  return y;
+}
+
+// Transposes the 4 x 4 digit grid of a thread's registers in place, in both halves of its 32 registers:
+// element 4a + b trades places with 4b + a, and 16 + 4a + b with 16 + 4b + a.
+template <typename T>
+__host__ __device__ inline void swap_thread_data(T* thread_data) {
+  for (int half = 0; half < 32; half += 16)
+    for (int a = 0; a < 4; ++a)
+      for (int b = a + 1; b < 4; ++b) {
+        const T t = thread_data[half + 4 * a + b];
+        thread_data[half + 4 * a + b] = thread_data[half + 4 * b + a];
+        thread_data[half + 4 * b + a] = t;
+      }
+}

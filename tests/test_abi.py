@@ -142,3 +142,40 @@ def test_synth_is_deterministic_and_bounded():
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     assert np.all(np.abs(a.real) <= 1) and np.all(np.abs(a.imag) <= 1)
     assert abs(a.real.mean()) < 0.1 and 0.5 < a.real.std() < 0.65
+
+
+def test_reference_helper_names_compile_and_compute(tmp_path):
+    """CHECK_CUDA, pad_h, reverse_bit_groups and swap_thread_data, the global-namespace names the reference's samples
+    use beside the device API (detail/util_cuda.h:10-18, detail/util_arith.h:16-30, 123-167): a host program that
+    includes the device header builds with hipcc and the helpers compute what the reference's do."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "helpers.hip"
+    src.write_text(r'''
+#include <thunderfft/thunderfft_device.hpp>
+#include <cstdio>
+int main() {
+  static_assert(reverse_bit_groups<2, 6>(0b000110) == 0b100100, "base-4 digit reversal");
+  static_assert(reverse_bit_groups<2, 7>(0b1000001) == 33, "leftover bit follows");
+  static_assert(pad_h(100) == -1 && pad_h(4096) > 0, "pad_h");
+  static_assert(8 * (4096 + pad_h(4096)) * thunderfft::batch_per_block<4096> >= thunderfft::workspace_bytes<4096>, "");
+  static_assert(8 * (256 + pad_h(256)) * thunderfft::batch_per_block<256> >= thunderfft::workspace_bytes<256>, "");
+  int v[32];
+  for (int i = 0; i < 32; ++i) v[i] = i;
+  swap_thread_data(v);
+  CHECK_CUDA(hipSuccess);
+  std::printf("%d %d %d %d %d %d\n", v[0], v[1], v[4], v[17], v[27], v[31]);
+  return 0;
+}
+''')
+    exe = tmp_path / "helpers"
+    lib_dir = os.path.join(ROOT, "fft_amd", "lib")
+    subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-I", os.path.join(ROOT, "include"),
+                    "-o", str(exe), str(src), "-L", lib_dir, "-lthunderfft_hip", f"-Wl,-rpath,{lib_dir}"],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=60).stdout
+    assert out.split() == ["0", "4", "1", "20", "30", "31"]
