@@ -76,7 +76,6 @@ struct BlockFFT {
   static constexpr int NG1 = (NB1 == 1) ? 1 : NB1 / 2, LPG1 = NRAW / NG1;
   static constexpr int NGL = (NBL == 1) ? 1 : NBL / 2, SPGL = NRAW / NGL;
   static constexpr bool kChainable = (R1 == RL);  // index_out == index_in: transforms can be chained in registers
-  static_assert(!P::MFMA_MID && !P::PREFETCH, "BlockFFT covers the plain VALU plans");
 
   // State is the thread id, the table and the workspace only: every index map below is a pure
   // function of the thread id (shifts and masks, all sizes being powers of two), recomputed where
@@ -277,8 +276,9 @@ struct BlockFFT {
   // The N-point transform on registers, unnormalised in both directions. In: first-pass order
   // (index_in); out: last-pass order (index_out). `lead`: the LDS buffer may still be read by a
   // previous transform() or by user code, so start with a barrier. The inverse runs the forward
-  // code on data with real and imaginary parts swapped.
-  template <bool FWD>
+  // code on data with real and imaginary parts swapped. EXCHANGE = false (a measurement build)
+  // leaves the LDS exchanges out: the butterflies alone, on the wrong data.
+  template <bool FWD, bool EXCHANGE = true>
   __device__ __forceinline__ void transform(c32 (&v)[E], bool lead) const {
     if constexpr (!FWD) {
 #pragma unroll
@@ -293,10 +293,10 @@ struct BlockFFT {
       for (int b = 0; b < NB2; ++b) w2[b] = tw[b2_n3(b) * R1];
     }
     butterflies<R1, 1>(v, w1);
-    exchange<1>(v, lead);
+    if constexpr (EXCHANGE) exchange<1>(v, lead);
     if constexpr (P::PASSES == 3) {
       butterflies<R2, 2>(v, w2);
-      exchange<2>(v, true);
+      if constexpr (EXCHANGE) exchange<2>(v, true);
     }
     butterflies<RL, 0>(v, nullptr);
     if constexpr (!FWD) {

@@ -23,8 +23,8 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
       // All three passes on the matrix cores (fft_mfma_kernel.hpp). Default: one workgroup per transform, pass-1
       // twiddles built incrementally, two LDS images. 12: the same with one LDS image; 5 / 6: one workgroup per
       // transform, twiddles from the lane-ordered table, one / two LDS images; 11 / 7: that kernel as a resident
-      // grid with row prefetch, two / one LDS images. Mode 3: the VALU kernel; 4: VALU with the middle pass on the
-      // matrix cores; 9: VALU kernel as a resident prefetching grid.
+      // grid with row prefetch, two / one LDS images. Mode 3: the VALU kernel; 9: VALU kernel as a resident
+      // prefetching grid.
       if (mode == 0 || mode == 10) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4, false, 16, true>() : make_mfma_entry<MfmaF16, false, true, 4, false, 16, true>(); return true; }
       if (mode == 12) { *out = forward ? make_mfma_entry<MfmaF16, true, false, 8, false, 16, true>() : make_mfma_entry<MfmaF16, false, false, 8, false, 16, true>(); return true; }
       if (mode == 11) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4, true>() : make_mfma_entry<MfmaF16, false, true, 4, true>(); return true; }
@@ -32,10 +32,9 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
       if (mode == 6) { *out = forward ? make_mfma_entry<MfmaF16, true, true, 4>() : make_mfma_entry<MfmaF16, false, true, 4>(); return true; }
       if (mode == 7) { *out = forward ? make_mfma_entry<MfmaF16, true, false, 4, true>() : make_mfma_entry<MfmaF16, false, false, 4, true>(); return true; }
       if (mode == 3) mode = 0;
-      else if (mode == 4) mode = 3;
-      else if (mode == 9) mode = 4;
+      else if (mode == 9) mode = 3;
       else if (mode != 1 && mode != 2) return false;
-      return entry_for<Plan4096, StoreF16, true, Plan4096Mfma, Plan4096ResidentSplit>(forward, mode, out);
+      return entry_for<Plan4096, StoreF16, true, Plan4096ResidentSplit>(forward, mode, out);
     case 8192:
       if (mfma_big_entry_for<MfmaF16, 2>(forward, mode, out)) return true;
       return entry_for<Plan8192Alt, StoreF16, false, Plan8192>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);

@@ -6,7 +6,7 @@
 // (thunderfft/include/thunderfft/detail/thunderfft_impl.cuh:14-32) and of its tuned
 // shared-memory layouts (thunderfft/include/thunderfft/thunderfft_layout_tuned.h:6-97).
 #pragma once
-#include "fft_lds_kernel.hpp"
+#include "fft_batch_kernel.hpp"
 #include "fft_dit_kernel.hpp"
 #include "fft_mfma_kernel.hpp"
 
@@ -38,9 +38,6 @@ using Plan2048Split = Plan<2048, 16, 16, 16, 8, 256, 7, 8, 5, 1, 5, kFlagSplit>;
 using Plan4096Split = Plan<4096, 16, 16, 16, 16, 256, 8, 16, 5, 1, 6, kFlagSplit>;
 using Plan8192Split = Plan<8192, 32, 32, 16, 16, 256, 8, 16, 5, 1, 4, kFlagSplit>;
 using Plan16384Split = Plan<16384, 32, 32, 32, 16, 512, 5, 1, 5, 1, 4, kFlagSplit>;
-
-// 16-bit storage, N = 4096: middle radix-16 pass on the matrix cores (fp16 operands, fp32 accumulate)
-using Plan4096Mfma = Plan<4096, 16, 16, 16, 16, 256, 8, 16, 5, 1, 4, kFlagSplit | kFlagMfmaMid>;
 
 // "Wide" three-pass forms of the short lengths: radix 4 or 8 first and last, so that the row
 // segments of the first-pass loads and last-pass stores are N/4 or N/8 points long (128 ... 512
