@@ -350,15 +350,17 @@ void run_one(const Args& a, int n) {
   // every other value is a plan of the transform itself
   tfft_exec_options opt;
   tfft_exec_options_init(&opt);
-  opt.plan = (a.mode == 1 || a.mode == 2) ? 0 : a.mode;
+  opt.plan = (a.mode >= 1 && a.mode <= 2) || a.mode == 13 || a.mode == 14 ? 0 : a.mode;
   opt.grid_blocks_per_cu = a.grid;
   opt.extra_lds = a.extra_lds;
   opt.grid_blocks = a.grid_blocks;
   opt.xcd_run_log2 = a.xcd;
   vec2_t<T>* dst = a.inplace ? d_perf : d_perf_out;
   const float ms = time_ms(s, 1, a.runs, [&] {
-    if (a.mode == 1 || a.mode == 2)
-      thunderfft::check(tfft_bench_access_pattern(thunderfft::dtype_code<T>(), n, 1, a.mode, d_perf, dst, batch, s, &opt), "bench");
+    // --mode 1 / 2 and 13 / 14: the measurement builds (patterns 1, 2 and 3, 4 of tfft_bench_access_pattern)
+    if (a.mode == 1 || a.mode == 2 || a.mode == 13 || a.mode == 14)
+      thunderfft::check(tfft_bench_access_pattern(thunderfft::dtype_code<T>(), n, 1, a.mode > 2 ? a.mode - 10 : a.mode, d_perf,
+                                                  dst, batch, s, &opt), "bench");
     else
       thunderfft::check(tfft_exec_c2c_opt(thunderfft::dtype_code<T>(), n, 1, d_perf, dst, batch, s, &opt), "bench");
   });

@@ -330,8 +330,12 @@ template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int 
           bool REPEAT = false>
 __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* in, u32x4_t* out,  // in and out may alias (in-place calls)
                                                                      const float2* __restrict__ tw, long long batch,
-                                                                     int xcd_log2, unsigned repeats = 1) {
+                                                                     int xcd_log2, unsigned repeats = 1,
+                                                                     unsigned io_mask = 3) {
   static_assert(!REPEAT || !PERSIST, "the repeat build is a one-shot kernel");
+  // measurement build only: bit 0 = load the tile's rows (else start from constants), bit 1 = store the result;
+  // run-time flags, so that the rest of the kernel is compiled as it stands
+  const bool do_loads = !REPEAT || (io_mask & 1u), do_stores = !REPEAT || (io_mask & 2u);
   static_assert(R1 == 1 || R1 == 2 || R1 == 4 || R1 == 8 || R1 == 16, "N = 256 R1");
   static_assert(!INCR || R1 > 1, "N = 256 has no first pass");
   constexpr int OUT_WORDS = mfma_out_words<R1>();
@@ -361,7 +365,12 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   };
   // tr is the position in the launch order, tile the 4096 points it stands for (xcd_chunk, fft_lds_kernel.hpp)
   long long tile = xcd_chunk(tr, tiles, xcd_log2);
-  request_rows(tile);
+  if (do_loads) {
+    request_rows(tile);
+  } else {
+#pragma unroll
+    for (int G = 0; G < 4; ++G) rows[G] = u32x4_t{0x3c003c00u, 0x38003800u, (unsigned)threadIdx.x, 0u};
+  }
 
   // ---- pass-1 twiddles in lane order, the DFT-16 matrix fragments, the pass-2 twiddles
   const float4* tw1 = reinterpret_cast<const float4*>(tabs) + tid;
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[mfma_out_slot<R1>(4 * (tid + 256 * q))]);
-    if (R1 == 16 || 4 * q + w <= last_cur) __builtin_nontemporal_store(v, dst + 256 * q);
+    if (do_stores && (R1 == 16 || 4 * q + w <= last_cur)) __builtin_nontemporal_store(v, dst + 256 * q);
   }
   if (!PERSIST || next >= tiles) break;
   __syncthreads();  // the output image is read before the next tile's pass 1 overwrites it

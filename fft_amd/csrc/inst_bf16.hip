@@ -41,7 +41,8 @@ bool lookup_bf16(int n, bool forward, int mode, KernelEntry* out) {
     default: return false;
   }
 }
-bool launch_repeat_bf16(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats, hipStream_t s) {
-  return launch_mfma_repeat_n<MfmaBF16Single>(n, in, out, tw, batch, repeats, s);
+bool launch_repeat_bf16(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats, unsigned io_mask,
+                        hipStream_t s) {
+  return launch_mfma_repeat_n<MfmaBF16Single>(n, in, out, tw, batch, repeats, io_mask, s);
 }
 }  // namespace tfft

@@ -174,28 +174,32 @@ KernelEntry make_mfma_entry() {
 // Measurement build of the default one-shot matrix-core kernel of N = 256 R1 (REPEAT: the passes run `repeats`
 // times per tile on chip). KernelEntry::launch has no slot for the count, so these are launched directly.
 template <class T16, int R1>
-void launch_mfma_repeat(const void* in, void* out, const float2* tw, long long batch, unsigned repeats, hipStream_t stream) {
+void launch_mfma_repeat(const void* in, void* out, const float2* tw, long long batch, unsigned repeats, unsigned io_mask,
+                        hipStream_t stream) {
   constexpr bool INCR = R1 > 1;
   constexpr bool DOUBLE = R1 != 1;  // the defaults: N = 256 one image, the others two
   const long long tiles = (batch * R1 + 15) / 16;
   fft_mfma4096_kernel<T16, true, DOUBLE, DOUBLE ? 4 : 8, false, R1, INCR, true>
       <<<dim3((unsigned)tiles), dim3(Mfma4096::WG), 0, stream>>>(static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out),
-                                                                 tw, batch, 4, repeats);
+                                                                 tw, batch, 4, repeats, io_mask);
 }
 template <class T16>
 bool launch_mfma_repeat_n(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats,
-                          hipStream_t stream) {
+                          unsigned io_mask, hipStream_t stream) {
   switch (n) {
-    case 256: launch_mfma_repeat<T16, 1>(in, out, tw, batch, repeats, stream); return true;
-    case 512: launch_mfma_repeat<T16, 2>(in, out, tw, batch, repeats, stream); return true;
-    case 1024: launch_mfma_repeat<T16, 4>(in, out, tw, batch, repeats, stream); return true;
-    case 2048: launch_mfma_repeat<T16, 8>(in, out, tw, batch, repeats, stream); return true;
-    case 4096: launch_mfma_repeat<T16, 16>(in, out, tw, batch, repeats, stream); return true;
+    case 256: launch_mfma_repeat<T16, 1>(in, out, tw, batch, repeats, io_mask, stream); return true;
+    case 512: launch_mfma_repeat<T16, 2>(in, out, tw, batch, repeats, io_mask, stream); return true;
+    case 1024: launch_mfma_repeat<T16, 4>(in, out, tw, batch, repeats, io_mask, stream); return true;
+    case 2048: launch_mfma_repeat<T16, 8>(in, out, tw, batch, repeats, io_mask, stream); return true;
+    case 4096: launch_mfma_repeat<T16, 16>(in, out, tw, batch, repeats, io_mask, stream); return true;
     default: return false;
   }
 }
-bool launch_repeat_f16(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats, hipStream_t s);
-bool launch_repeat_bf16(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats, hipStream_t s);
+// io_mask: bit 0 = with the tile's loads, bit 1 = with its stores (3 = the whole kernel)
+bool launch_repeat_f16(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats, unsigned io_mask,
+                       hipStream_t s);
+bool launch_repeat_bf16(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats, unsigned io_mask,
+                        hipStream_t s);
 
 // The matrix-core kernels of one 16-bit storage type for N = 256 R1 < 4096. Mode 0, the default: N = 256 (no first
 // pass, no twiddle table to fetch) one workgroup per tile with one LDS image; otherwise a resident grid with the

@@ -661,16 +661,24 @@ int tfft_exec_c2c_static(int dtype, int n, int forward, const void* d_in, void* 
   return finish_launch(s);
 }
 
+static int exec_half_traffic(int dtype, int n, int pattern, const void* d_in, void* d_out, long long batch, hipStream_t s);
+
 int tfft_bench_access_pattern(int dtype, int n, int forward, int pattern, const void* d_in, void* d_out,
                               long long batch, void* stream, const tfft_exec_options* options) {
   ExecOpts opt;
   if (int rc = parse_options("tfft_bench_access_pattern", options, &opt)) return rc;
-  if (pattern != 1 && pattern != 2)
-    return fail(TFFT_ERR_INVALID, "tfft_bench_access_pattern: pattern %d (1 = loads and stores only, 2 = no LDS exchange)",
-                pattern);
+  if (pattern < 1 || pattern > 4)
+    return fail(TFFT_ERR_INVALID,
+                "tfft_bench_access_pattern: pattern %d (1 = loads and stores only, 2 = no LDS exchange, 3 = no stores, "
+                "4 = no loads)", pattern);
   if (opt.plan != 0) return fail(TFFT_ERR_INVALID, "tfft_bench_access_pattern: measures the default kernel only");
   if (int rc = check_io("tfft_bench_access_pattern", d_in, d_out, batch)) return rc;
   if (batch == 0) return TFFT_OK;
+  if (pattern >= 3) {
+    if (dtype != TFFT_F16 && dtype != TFFT_BF16)
+      return fail(TFFT_ERR_UNSUPPORTED, "tfft_bench_access_pattern: patterns 3 and 4 are builds of the 16-bit matrix-core kernels");
+    return exec_half_traffic(dtype, n, pattern, d_in, d_out, batch, static_cast<hipStream_t>(stream));
+  }
   return exec_small("tfft_bench_access_pattern", dtype, n, forward, pattern, d_in, d_out, batch,
                     static_cast<hipStream_t>(stream), opt);
 }
@@ -694,9 +702,29 @@ int tfft_bench_onchip_repeats(int dtype, int n, int repeats, const void* d_in, v
     plan = it->second;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool ok = dtype == TFFT_F16 ? tfft::launch_repeat_f16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, s)
-                                    : tfft::launch_repeat_bf16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, s);
+  const bool ok = dtype == TFFT_F16 ? tfft::launch_repeat_f16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, 3u, s)
+                                    : tfft::launch_repeat_bf16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, 3u, s);
   if (!ok) return fail(TFFT_ERR_UNSUPPORTED, "tfft_bench_onchip_repeats: n = 256 ... 4096");
+  return finish_launch(s);
+}
+
+// patterns 3 and 4 of tfft_bench_access_pattern: the matrix-core kernel of a 16-bit length without its stores / loads
+static int exec_half_traffic(int dtype, int n, int pattern, const void* d_in, void* d_out, long long batch, hipStream_t s) {
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  DevicePlan plan;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+    if (it == g_plans.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_bench_access_pattern: call tfft_initialize(%s, %d) on device %d first",
+                  dtype_name(dtype), n, dev);
+    plan = it->second;
+  }
+  const unsigned io_mask = pattern == 3 ? 1u : 2u;
+  const bool ok = dtype == TFFT_F16 ? tfft::launch_repeat_f16(n, d_in, d_out, plan.tw, batch, 1u, io_mask, s)
+                                    : tfft::launch_repeat_bf16(n, d_in, d_out, plan.tw, batch, 1u, io_mask, s);
+  if (!ok) return fail(TFFT_ERR_UNSUPPORTED, "tfft_bench_access_pattern: patterns 3 and 4 cover n = 256 ... 4096");
   return finish_launch(s);
 }
 

@@ -104,7 +104,8 @@ def test_no_option_can_select_a_wrong_result_build():
     bad = fft_amd.exec_options({"plan": 3})
     bad.struct_size = 4
     assert lib.tfft_exec_c2c_opt(0, 4096, 1, ptr, ptr, 1, None, bad) == 3
-    assert lib.tfft_bench_access_pattern(0, 4096, 1, 3, ptr, ptr, 1, None, None) == 3
+    assert lib.tfft_bench_access_pattern(0, 4096, 1, 5, ptr, ptr, 1, None, None) == 3
+    assert lib.tfft_bench_access_pattern(0, 4096, 1, 3, ptr, ptr, 1, None, None) == 1  # patterns 3, 4: 16-bit kernels only
     assert lib.tfft_bench_access_pattern(0, 4096, 1, 1, ptr, ptr, 1, None, fft_amd.exec_options({"plan": 3})) == 3
     with pytest.raises(fft_amd.ThunderFFTError):
         fft_amd.exec_options({"no_such_field": 1})
