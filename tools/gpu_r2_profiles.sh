@@ -1,5 +1,5 @@
 #!/bin/bash
-# The tracked profiles of this round: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE of bench.py per configuration.
+# The tracked profiles: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE of bench.py per configuration.
 set -u
 run() { tag=$1; shift; PROF_DIR=prof_$tag BENCH_ARGS="$*" bash tools/gpu_profile.sh > gpurun_out/prof_$tag.log 2>&1 || { tail -5 gpurun_out/prof_$tag.log; exit 1; }; echo "done $tag"; }
 mkdir -p gpurun_out

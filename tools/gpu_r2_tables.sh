@@ -1,5 +1,5 @@
 #!/bin/bash
-# The tables tracked under profiles/ for this round (text output of bench/tfft_bench).
+# The benchmark tables tracked under profiles/ (text output of bench/tfft_bench, SQ counter summaries).
 set -u
 O=gpurun_out/r02_tables; rm -rf $O; mkdir -p $O
 B=./bench/tfft_bench
