@@ -280,6 +280,40 @@ def test_full_size_16bit_configuration(oracle_mod, kind):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("kind,n", (("fp32", 4096), ("fp32", 8192), ("fp32", 64), ("fp16", 1024), ("bf16", 16384)))
+def test_more_than_2_to_the_32_points(oracle_mod, kind, n):
+    """Offsets beyond 2^31 (and 2^32) points: one in-place launch over a little more than 2^32 points (32 GiB of
+    fp32, 16 GiB of 16-bit data). Transforms at the start, around the 2^31- and 2^32-point marks and at the very
+    end are compared with the oracle; everything in between must at least have been transformed (Parseval on a
+    strided sample)."""
+    batch = (1 << 32) // n + 3
+    dt = TORCH_DT[kind]
+    x = torch.empty(batch, n, 2, device="cuda", dtype=dt)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    step = 1 << 16
+    for b0 in range(0, batch, step):  # filled in slices: no second 32 GiB temporary
+        b1 = min(batch, b0 + step)
+        x[b0:b1] = ((torch.rand(b1 - b0, n, 2, device="cuda", generator=g) * 2 - 1) / n ** 0.5).to(dt)
+    half, full = (1 << 31) // n, (1 << 32) // n
+    idx = sorted({0, 1, half - 1, half, half + 1, full - 1, full, full + 1, batch - 1})
+    sample = list(range(7, batch, max(1, batch // 257)))
+    keep_in = x[idx].clone()
+    e_in = (x[sample].float() ** 2).sum(dim=(1, 2), dtype=torch.float64)
+    fft_amd.ThunderFFTInitialize(kind, n)
+    fft_amd.ThunderFFT_global(x, x, batch, n, True)
+    torch.cuda.synchronize()
+    tol = TOL[kind]
+    xs = keep_in.float().cpu().numpy().astype(np.float64)
+    Xs = x[idx].float().cpu().numpy().astype(np.float64)
+    ref = oracle_mod.fft(xs[..., 0] + 1j * xs[..., 1], True)
+    for k in range(len(idx)):
+        assert oracle_mod.rel_l2(Xs[k, :, 0] + 1j * Xs[k, :, 1], ref[k]) <= tol, (kind, n, idx[k])
+    e_out = (x[sample].float() ** 2).sum(dim=(1, 2), dtype=torch.float64) / n
+    assert torch.max(torch.abs(e_out / e_in - 1)).item() < (1e-5 if kind == "fp32" else 2 * tol)
+    del x
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("mode", [3, 4])
 @pytest.mark.parametrize("n", ALL_N)
 def test_alternative_plans_vs_oracle(oracle_mod, n, mode):
