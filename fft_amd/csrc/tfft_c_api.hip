@@ -543,12 +543,23 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
   if (it == g_big.end())
     return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
   BigPlan& p = it->second;
-  if (p.used && p.last_stream != s) TFFT_HIP(hipStreamWaitEvent(s, p.done, 0));
+  // A stream under graph capture cannot wait on, or record, an event of the eager world: a captured call is ordered
+  // inside its graph only, and keeping its replays apart from other users of the scratch is the caller's business
+  // (tfft_exec_c2c_static and a caller workspace exist for exactly that).
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &capture) != hipSuccess) {
+    (void)hipGetLastError();
+    capture = hipStreamCaptureStatusNone;
+  }
+  const bool eager = capture == hipStreamCaptureStatusNone;
+  if (eager && p.used && p.last_stream != s) TFFT_HIP(hipStreamWaitEvent(s, p.done, 0));
   const int rc = enqueue_big(p, n, forward != 0, d_in, d_out, batch, p.work, p.work_batch, opt.xcd_run_log2, s);
-  // recorded even after a failed sweep: whatever was enqueued still uses the scratch
-  TFFT_HIP(hipEventRecord(p.done, s));
-  p.used = true;
-  p.last_stream = s;
+  if (eager) {
+    // recorded even after a failed sweep: whatever was enqueued still uses the scratch
+    TFFT_HIP(hipEventRecord(p.done, s));
+    p.used = true;
+    p.last_stream = s;
+  }
   return rc;
 }
 

@@ -56,6 +56,27 @@ def test_static_in_place_and_full_scratch():
     assert torch.equal(y, want)
 
 
+def test_static_entry_under_graph_capture():
+    """The callers this entry point exists for: captured into a HIP graph (no allocation, no synchronisation, no
+    event of the eager world) and replayed, it gives the eager result every time."""
+    n, batch = 1 << 16, 3
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    want = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x, want, batch, n, True)
+    torch.cuda.synchronize()
+    out = torch.zeros_like(x)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        exec_static(x, out, batch, n, True)  # on the capture stream (torch's current stream)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+
+
 def test_static_limits_and_forwarding():
     n = 1 << 21
     x = torch.zeros(1, n, 2, device="cuda")
