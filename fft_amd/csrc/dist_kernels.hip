@@ -47,12 +47,34 @@ __global__ __launch_bounds__(256) void dist_permute_kernel(const float2* __restr
     p = FWD ? make_float2(v.x, v.y) : make_float2(v.y, v.x);
     q = FWD ? make_float2(v.z, v.w) : make_float2(v.w, v.z);
   };
-  auto twiddle = [&](c32 v, long long i, long long j) {
+  // Four-step twiddles of this thread's two columns j, j + 1 for its rows i = i0 + row0 + 8 k, k < 8:
+  //   W^(p_k q) = W^(p_0 q) (W^(8 pi q))^k,   p_k = tw_p0 + tw_pi i,
+  // so two table look-ups per column (base and step) and a short power tree replace a look-up per element
+  // (the gathers of a look-up per element, not the arithmetic, were what this pass spent its time on).
+  c32 tw_k[2][kTile / 8];
+  if constexpr (TWIDDLE) {
+    auto root = [&](unsigned long long e) {
+      e &= (unsigned long long)(a.tw_n - 1);
+      return tfft::cmul(tw_hi[e >> a.tw_shift], tw_lo[e & ((1ull << a.tw_shift) - 1)]);
+    };
+    const unsigned long long mask = (unsigned long long)(a.tw_n - 1);
+    const unsigned long long p_first = (unsigned long long)(a.tw_p0 + a.tw_pi * (i0 + row0)) & mask;
+    const unsigned long long p_step = (unsigned long long)(8 * a.tw_pi) & mask;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned long long q =
+          (unsigned long long)(a.tw_q0 + a.tw_qb1 * b1 + a.tw_qb2 * b2 + a.tw_qj * (j0 + lane2 + c)) & mask;
+      const c32 base = root(p_first * q);
+      c32 pw[kTile / 8];
+      tfft::twiddle_powers<kTile / 8>(root(p_step * q), pw);
+      tw_k[c][0] = base;
+#pragma unroll
+      for (int k = 1; k < kTile / 8; ++k) tw_k[c][k] = tfft::cmul(base, pw[k]);
+    }
+  }
+  auto twiddle = [&](c32 v, int k, int c) {
     if constexpr (!TWIDDLE) return v;
-    const unsigned long long p = (unsigned long long)(a.tw_p0 + a.tw_pi * i);
-    const unsigned long long q = (unsigned long long)(a.tw_q0 + a.tw_qb1 * b1 + a.tw_qb2 * b2 + a.tw_qj * j);
-    const unsigned long long e = (p * q) & (unsigned long long)(a.tw_n - 1);
-    return tfft::cmul(v, tfft::cmul(tw_hi[e >> a.tw_shift], tw_lo[e & ((1ull << a.tw_shift) - 1)]));
+    return tfft::cmul(v, tw_k[c][k]);
   };
   auto store2 = [&](float2* p, c32 x, c32 y) {
     const f32x4_t v = FWD ? f32x4_t{x.x, x.y, y.x, y.y} : f32x4_t{x.y, x.x, y.y, y.x};
@@ -67,7 +89,7 @@ __global__ __launch_bounds__(256) void dist_permute_kernel(const float2* __restr
       if (i < a.ni && j < a.nj) {
         c32 p, q;
         load2(i, j, p, q);
-        store2(dst + i * a.out_j + j, twiddle(p, i, j), twiddle(q, i, j + 1));
+        store2(dst + i * a.out_j + j, twiddle(p, k, 0), twiddle(q, k, 1));
       }
     }
   } else {
@@ -78,8 +100,8 @@ __global__ __launch_bounds__(256) void dist_permute_kernel(const float2* __restr
       if (i < a.ni && j < a.nj) {
         c32 p, q;
         load2(i, j, p, q);
-        tile[r][lane2] = twiddle(p, i, j);
-        tile[r][lane2 + 1] = twiddle(q, i, j + 1);
+        tile[r][lane2] = twiddle(p, k, 0);
+        tile[r][lane2 + 1] = twiddle(q, k, 1);
       }
     }
     __syncthreads();
@@ -116,12 +138,17 @@ __global__ __launch_bounds__(256) void dist_radix_kernel(const float2* in, float
     }
     tfft::dft<P>(x);
     tfft::dft<P>(y);
-    const long long m_mask = (long long)P * a.row_len - 1;
+    // W_M^(t k) and W_M^((t + 1) k), k < P, as powers of the two adjacent table entries W_M^t, W_M^(t + 1) (one
+    // coalesced 16-byte load; gathering every power from the table would cost more cache lines than the data)
+    const f32x4_t w = *reinterpret_cast<const f32x4_t*>(tab + t);
+    c32 px[P], py[P];
+    tfft::twiddle_powers<P>(make_float2(w.x, w.y), px);
+    tfft::twiddle_powers<P>(make_float2(w.z, w.w), py);
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       if (k > 0) {
-        x[k] = tfft::cmul(x[k], tab[(t * k) & m_mask]);
-        y[k] = tfft::cmul(y[k], tab[((t + 1) * k) & m_mask]);
+        x[k] = tfft::cmul(x[k], px[k]);
+        y[k] = tfft::cmul(y[k], py[k]);
       }
       const f32x4_t v = FWD ? f32x4_t{x[k].x, x[k].y, y[k].x, y[k].y} : f32x4_t{x[k].y, x[k].x, y[k].y, y[k].x};
       __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(out + k * a.out_chunk + row * a.out_pitch + t));
