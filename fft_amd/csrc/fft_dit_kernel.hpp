@@ -6,7 +6,8 @@
 //   x[2 m + r] -> F_r[k'] (4096 points each),   X[k' + 4096 k0] = F_0[k'] + (-1)^k0 W_N^k' F_1[k'],
 // F_0 and F_1 run one after the other through the 4096-point block transform (fft_block.hpp) and its 34 KiB
 // exchange buffer, and the last step is a radix-2 butterfly between registers of one thread. A workgroup keeps
-// the 256 threads and the LDS footprint of the N = 4096 kernel, so four workgroups share a CU: 76-77 %.
+// the 256 threads and the LDS footprint of the N = 4096 kernel, so four workgroups share a CU: 76-77 %, and
+// 78-79 % with the scheduler's max-ILP strategy (set for this translation unit in the Makefile).
 //   loads  : x[2 m] and x[2 m + 1] are 16 contiguous bytes, one load of the lane that owns column m:
 //            de-interleaving is register naming, and the 64 lanes of a wave read one contiguous kilobyte
 //   stores : block k0 of the result is 4096 contiguous points in the register order the 4096-point transform

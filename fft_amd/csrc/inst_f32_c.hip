@@ -4,7 +4,7 @@ namespace tfft {
 bool lookup_f32_c(int n, bool forward, int mode, KernelEntry* out) {
   switch (n) {
     case 8192:
-      // default: two 4096-point transforms per workgroup, four workgroups per CU (fft_dit_kernel.hpp; 76-77 % of
+      // default: two 4096-point transforms per workgroup, four workgroups per CU (fft_dit_kernel.hpp; 78-79 % of
       // 8 TB/s against 72 % for the one-pass plan with 32 points per thread, which LDS limits to two workgroups per
       // CU). Plans 3 and 4: the one-pass kernels (full and split exchange); the measurement builds price the
       // one-pass kernel's access pattern.
