@@ -290,11 +290,10 @@ class DistributedFFT:
             did()
             if P > 1:
                 yield a, b
-            else:
-                a, b = b, a
-            if P > 1:
                 ops.radix(b, b, self._spec_1a(False), forward)
                 did()
+            else:
+                a, b = b, a
         else:
             if P > 1:
                 ops.radix(x, b, self._spec_1a(True), forward)
