@@ -24,7 +24,7 @@ CONVBENCH  := bench/thff_conv1d_fullfft4096 bench/thff_conv1d bench/thff_fft
 
 .PHONY: all lib oracle bench examples clean
 all: lib oracle bench examples
-examples: examples/libspectral_mask.so
+examples: examples/libspectral_mask.so examples/libreference_shape.so
 lib: $(LIB)
 oracle: $(ORACLE)
 bench: $(BENCH) $(CONVBENCH)
@@ -49,7 +49,7 @@ $(BENCH): bench/tfft_bench.cpp bench/stat.hpp include/thunderfft/thunderfft.cuh 
 	$(HIPCC) -O3 -std=c++17 -fno-slp-vectorize --offload-arch=$(ARCH) -Iinclude -o $@ bench/tfft_bench.cpp \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
-bench/thff_conv1d%: bench/thff_conv1d%.cpp bench/harness.hpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+bench/thff_conv1d%: bench/thff_conv1d%.cpp bench/harness.hpp include/thunderfft/thunderfft.cuh include/thunderfft/thunderfft_device.hpp include/thunderfft_c.h $(LIB)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
 	    -L$(LIBDIR) -lthunderfft_hip -L/opt/rocm/lib -lhipfft -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
@@ -65,5 +65,9 @@ bench/thff_conv1d: bench/thff_conv1d.cpp bench/harness.hpp include/thunderfft/th
 examples/libspectral_mask.so: examples/spectral_mask.hip include/thunderfft/thunderfft_device.hpp $(KERNEL_HDRS) $(LIB)
 	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $< -L$(LIBDIR) -lthunderfft_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
+# user kernels written against the reference's own device-level signatures
+examples/libreference_shape.so: examples/reference_shape.hip include/thunderfft/thunderfft.cuh include/thunderfft/thunderfft_device.hpp include/thunderfft/thunderfft_layout_tuned.h $(KERNEL_HDRS) $(LIB)
+	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $< -L$(LIBDIR) -lthunderfft_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
 clean:
-	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH) $(CONVBENCH) examples/libspectral_mask.so
+	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH) $(CONVBENCH) examples/libspectral_mask.so examples/libreference_shape.so

@@ -68,7 +68,17 @@ struct io_is_real : std::false_type {};
 template <>
 struct io_is_real<StoreRealF16> : std::true_type {};
 
-template <class P>
+// (cos, -sin)(2 pi k / n) evaluated on the spot: k / n is exact for the power-of-two lengths here, so sincospif
+// keeps its full accuracy. Stands in for a table entry when a kernel has no table at hand (the reference
+// evaluates every twiddle this way, with fast-math intrinsics: rotate(), detail/util_arith.h:85-91).
+__device__ __forceinline__ c32 unit_root(int k, int n) {
+  float s, c;
+  sincospif(-2.0f * (float)k / (float)n, &s, &c);
+  return make_float2(c, s);
+}
+
+// TW_OPTIONAL: a null table pointer is allowed and means "evaluate the twiddle bases in the kernel".
+template <class P, bool TW_OPTIONAL = false>
 struct BlockFFT {
   static constexpr int N = P::N, E = P::E, R1 = P::R1, R2 = P::R2, R3 = P::R3, RL = P::RL, WG = P::WG;
   static constexpr int C1 = P::C1, C2 = P::C2, CL = P::CL, NB1 = P::NB1, NB2 = P::NB2, NBL = P::NBL;
@@ -94,6 +104,14 @@ struct BlockFFT {
     tw = tw_;
     lds2 = reinterpret_cast<float2*>(lds);
     lds1 = reinterpret_cast<float*>(lds);
+  }
+
+  // table entry W_N^k
+  __device__ __forceinline__ c32 twiddle(int k) const {
+    if constexpr (TW_OPTIONAL) {
+      if (tw == nullptr) return unit_root(k, N);
+    }
+    return tw[k];
   }
 
   // ---- butterflies of a thread. First and last pass: butterfly b handles column g % C of
@@ -287,10 +305,10 @@ struct BlockFFT {
     // twiddle bases, one per butterfly: W_N^c after the first pass, W_{R2 R3}^{n3} after the middle one
     c32 w1[NB1], w2[NB2];
 #pragma unroll
-    for (int b = 0; b < NB1; ++b) w1[b] = tw[b1_c(b)];
+    for (int b = 0; b < NB1; ++b) w1[b] = twiddle(b1_c(b));
     if constexpr (P::PASSES == 3) {
 #pragma unroll
-      for (int b = 0; b < NB2; ++b) w2[b] = tw[b2_n3(b) * R1];
+      for (int b = 0; b < NB2; ++b) w2[b] = twiddle(b2_n3(b) * R1);
     }
     butterflies<R1, 1>(v, w1);
     if constexpr (EXCHANGE) exchange<1>(v, lead);

@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "../thunderfft_c.h"
 
@@ -65,15 +66,30 @@ inline void check(int rc, const char* what) {
   if (rc != TFFT_OK) throw std::runtime_error(std::string("[ThunderFFT] ") + what + ": " + tfft_last_error());
 }
 
+namespace detail {
+// The reference publishes its table addresses to device code through module-scope __constant__ pointer symbols
+// (detail/thunderfft_impl_twiddle.cuh:42-50, 298-301). Device symbols are per translation unit here, so every
+// unit that includes the device-level API (thunderfft_device.hpp) registers a function that writes the unit's own
+// symbol, and Initialize / Finalize call them all: (dtype, n) after a table was built, (dtype, 0) after the
+// tables of dtype were freed.
+using table_publisher = void (*)(int dtype, int n);
+inline std::vector<table_publisher>& table_publishers() {
+  static std::vector<table_publisher> list;
+  return list;
+}
+}  // namespace detail
+
 // Persistent twiddle management (reference thunderfft.cuh:39-44).
 template <typename T>
 inline void ThunderFFTInitialize(int N) {
   check(tfft_initialize(dtype_code<T>(), N), "ThunderFFTInitialize");
+  for (auto publish : detail::table_publishers()) publish(dtype_code<T>(), N);
 }
 
 template <typename T>
 inline void ThunderFFTFinalize() {
   check(tfft_finalize(dtype_code<T>()), "ThunderFFTFinalize");
+  for (auto publish : detail::table_publishers()) publish(dtype_code<T>(), 0);
 }
 
 // Launch wrapper (reference thunderfft.cuh:98-102, detail/thunderfft_impl_kernel.cuh:6-30).
@@ -106,3 +122,9 @@ inline tfft_plan_info plan_info(int N) {
 }
 
 }  // namespace thunderfft
+
+// Like the reference's header (thunderfft.cuh:135 pulls in its device code), one include gives a HIP translation
+// unit the device-level calls as well. Define THUNDERFFT_HOST_API_ONLY to keep a unit to the three host calls.
+#if defined(__HIPCC__) && !defined(THUNDERFFT_HOST_API_ONLY)
+#include "thunderfft_device.hpp"
+#endif

@@ -20,7 +20,8 @@ def pytest_sessionstart(session):
     lib = os.path.join(ROOT, "fft_amd", "lib", "libthunderfft_hip.so")
     ora = os.path.join(ROOT, "oracle", "liboracle_dft.so")
     ex = os.path.join(ROOT, "examples", "libspectral_mask.so")
-    if not (os.path.exists(lib) and os.path.exists(ora) and os.path.exists(ex)):
+    ex2 = os.path.join(ROOT, "examples", "libreference_shape.so")
+    if not (os.path.exists(lib) and os.path.exists(ora) and os.path.exists(ex) and os.path.exists(ex2)):
         subprocess.check_call(["make", "-C", ROOT, "-j8", "lib", "oracle", "examples"], stdout=subprocess.DEVNULL)
 
 
