@@ -220,6 +220,92 @@ def test_distributed_virtual_ranks_hip(oracle_mod, world, lg):
             assert err <= 2e-6, (r, err)
 
 
+def _direct_bins_fp64(x, ks, chunk=1 << 24):
+    """X[k] = sum_n x[n] exp(-2 pi i n k / N) for the bins ks, summed in fp64 on the device straight from the
+    definition (n k mod N is exact in int64; every cos / sin is an fp64 evaluation). x: [N, 2] float32."""
+    n = x.shape[0]
+    kt = torch.tensor(ks, dtype=torch.int64, device=x.device)
+    acc = torch.zeros(len(ks), 2, dtype=torch.float64, device=x.device)
+    for s in range(0, n, chunk):
+        idx = torch.arange(s, min(n, s + chunk), dtype=torch.int64, device=x.device)
+        xr, xi = x[s:s + chunk, 0].double(), x[s:s + chunk, 1].double()
+        for g in range(0, len(ks), 4):
+            ang = ((idx[None, :] * kt[g:g + 4, None]) % n).double() * (-2.0 * np.pi / n)
+            c, sn = torch.cos(ang), torch.sin(ang)
+            acc[g:g + 4, 0] += (xr * c - xi * sn).sum(dim=1)
+            acc[g:g + 4, 1] += (xr * sn + xi * c).sum(dim=1)
+    return acc
+
+
+def _rel(a, b):
+    return (torch.linalg.vector_norm((a - b).double()) / torch.linalg.vector_norm(b.double())).item()
+
+
+def test_distributed_2p30_on_eight_virtual_ranks():
+    """The 8-GPU configuration's single large transform, 2^30 points over 8 ranks (1 GiB per rank, R1 = C2 = 4096),
+    with all eight ranks' passes stepped on the one GPU and the exchanges as chunk copies. Checked three ways:
+    against tfft_exec_c2c(n = 2^30) on the same input (a different algorithm: three strided sweeps), against fp64
+    direct sums of the definition at 40 scattered bins (five per rank's shard), and by an inverse round trip.
+    Natural and transposed layouts."""
+    from fft_amd.distributed import DistributedFFT, HipOps, run_virtual
+
+    world, n = 8, 1 << 30
+    free, _ = torch.cuda.mem_get_info()
+    if free < 64 * 2 ** 30:
+        pytest.skip("needs about 50 GiB of free device memory")
+    g = torch.Generator(device="cuda").manual_seed(30)
+    x = torch.rand(n, 2, device="cuda", generator=g) * 2 - 1
+    ops = HipOps()
+    plans = [DistributedFFT(n, ops=ops, rank=r, world=world) for r in range(world)]
+    per, n1, n2, r1, c2 = n // world, plans[0].n1, plans[0].n2, plans[0].r1, plans[0].c2
+    assert (n1, n2, r1, c2) == (1 << 15, 1 << 15, 4096, 4096)
+
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    X = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x.view(1, n, 2), X.view(1, n, 2), 1, n, True)
+
+    rng = np.random.default_rng(30)
+    ks = sorted({r * per + int(o) for r in range(world) for o in [0, per - 1, *rng.integers(1, per - 1, 3)]})
+    want = _direct_bins_fp64(x, ks)
+    scale = torch.linalg.vector_norm(want).item()
+    kt = torch.tensor(ks, device="cuda")
+    assert torch.linalg.vector_norm(X[kt].double() - want).item() <= 2e-6 * scale
+
+    # natural order in and out: 8 passes, 3 exchanges
+    res = run_virtual(plans, [x[r * per:(r + 1) * per] for r in range(world)], True)
+    torch.cuda.synchronize()
+    assert plans[0].passes == 8
+    got_bins = torch.stack([res[k // per].reshape(per, 2)[k % per] for k in ks])
+    assert torch.linalg.vector_norm(got_bins.double() - want).item() <= 2e-6 * scale
+    for r in range(world):
+        # two fp32 results of different algorithms, each within about 8e-7 of the exact spectrum at this length
+        err = _rel(res[r].reshape(per, 2), X[r * per:(r + 1) * per])
+        assert err <= 2e-6, f"rank {r}: distributed vs single-GPU transform rel_l2={err:.3e}"
+
+    # inverse of the distributed result, rank by rank from copies (the results live in the plans' work buffers)
+    spectrum = [t.reshape(per, 2).clone() for t in res]
+    back = run_virtual(plans, spectrum, False)
+    torch.cuda.synchronize()
+    for r in range(world):
+        err = _rel(back[r].reshape(per, 2) / n, x[r * per:(r + 1) * per])
+        assert err <= 2e-6, f"rank {r}: round trip rel_l2={err:.3e}"
+    del spectrum, back
+
+    # transposed layouts on both sides: 5 passes, ONE exchange
+    cols = [x.view(n1, n2, 2)[:, r * c2:(r + 1) * c2].transpose(0, 1).contiguous() for r in range(world)]
+    res = run_virtual(plans, cols, True, input_layout="transposed", output_layout="transposed")
+    torch.cuda.synchronize()
+    assert plans[0].passes == 5
+    Xk = X.view(c2, world, n1, 2)  # X[k1 + N1 (ks + P kc)] as [kc][ks][k1]
+    for r in range(world):
+        expect = Xk[:, :, r * r1:(r + 1) * r1].permute(1, 2, 0, 3)  # [ks][k1l][kc], the rank's transposed output
+        err = _rel(res[r], expect)
+        assert err <= 2e-6, f"rank {r}: transposed layout rel_l2={err:.3e}"
+    del cols, res, plans, ops, X, x
+    fft_amd.ThunderFFTFinalize("fp32")
+    torch.cuda.empty_cache()
+
+
 def test_dist_pass_kernels_match_their_definition():
     """tfft_dist_permute and tfft_dist_radix against the fp64 evaluation of their definitions (NumpyOps) on
     shapes that are not multiples of the 64 x 64 tile, with batch strides, with and without the twiddle, both
