@@ -144,7 +144,8 @@ int tfft_set_option(const char* key, long long value);
 /* MEASUREMENT ONLY -- the output is meaningless. Runs the default kernel of (dtype, n) with part of its work
  * compiled out, to price the rest: pattern 1 = the global loads and stores alone (the rows are read and written
  * in the transform's access pattern), pattern 2 = loads, butterflies and stores without the LDS exchanges
- * (fp32, n <= 16384, lengths that have the build); patterns 3 and 4 = the matrix-core kernel of a 16-bit length
+ * (fp32, n <= 16384, lengths that have the build; for fp32 n = 8192 the builds are those of the one-pass
+ * 32 x 16 x 16 kernel, plan 3, not of the default two-transform kernel); patterns 3 and 4 = the matrix-core kernel of a 16-bit length
  * (fp16 / bf16, n = 256 ... 4096) without its stores / without its loads: what the read stream and the write
  * stream of that kernel cost each on its own. Kept apart from tfft_exec_c2c so that no option can make a
  * transform call return wrong data. No reference counterpart (its bench prices on-chip time with in-kernel
