@@ -32,6 +32,13 @@ def filter_layout(h_freq, N, stream=None, options=None):
     return out
 
 
+def forget_layout(buf):
+    """Drops what the library recorded about the register order `buf` holds (see tfft_conv_forget_layout): call it
+    after refilling a permuted-filter buffer by other means than filter_layout."""
+    with torch.cuda.device(buf.device):
+        _check(_lib.load().tfft_conv_forget_layout(buf.data_ptr(), buf.numel() * buf.element_size()))
+
+
 def filter_spectra(h_time, N, stream=None, options=None):
     """Filter taps [D, K, 2] (already scaled by 1/N if the caller wants a normalised result, as the
     reference does at :352-361) -> register-order spectra [D, N, 2] of the same element type."""

@@ -16,7 +16,7 @@ namespace tfft {
 // ("Full": fewer barriers, ~34 KiB of LDS for 4096 points, 4 workgroups per CU) and real parts
 // then imaginary parts through a 4-byte-per-point buffer ("Split": twice the barriers, half the
 // LDS, 6-8 workgroups per CU). The default of each length is the one that measured faster on
-// MI355X at 2^28 points; the other stays reachable as the A/B plan (tfft_set_option("mode", 3)).
+// MI355X at 2^28 points; the other stays reachable as the A/B plan (tfft_exec_options.plan = 3).
 //
 //                           N      E   R1  R2  R3  WG   PS1 PW1 PS2 PW2 MINW FLAGS
 using Plan64Full = Plan<64, 16, 16, 4, 1, 256, 5, 1, 0, 0>;
@@ -97,6 +97,7 @@ struct KernelEntry {
   int resident_per_cu = 0;  // > 0: a resident grid of this many workgroups per CU is the kernel's default launch
   int xcd_log2 = 0;         // log2 of the run of consecutive chunks one XCD takes (xcd_chunk in fft_lds_kernel.hpp)
   int xcd_log2_in_place = -1;  // the same for in-place calls (-1: as xcd_log2)
+  bool one_workgroup_per_transform = false;  // grid = batch, whatever LaunchShape::grid says (no resident form)
 };
 
 // Measured best run of consecutive chunks per XCD (interleaved A/B at 2^28 points). Out of place the rate also
@@ -239,6 +240,7 @@ KernelEntry make_mfma_big_entry() {
   e.radix[2] = 1;
   e.lds_bytes = 4 * 2 * mfma_out_words<16>();
   e.xcd_log2 = 4;
+  e.one_workgroup_per_transform = true;
   return e;
 }
 
@@ -266,6 +268,7 @@ KernelEntry make_dit_entry() {
   e.radix[2] = 1;
   e.lds_bytes = Plan4096Full::LDS_BYTES;
   e.xcd_log2 = 3;  // runs of 8 transforms (512 KiB) per XCD: 76.6-76.8 % against 76.2 (16), 74.7 (32), 72.1 (4)
+  e.one_workgroup_per_transform = true;
   return e;
 }
 

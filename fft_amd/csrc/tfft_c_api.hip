@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -73,7 +74,6 @@ struct BigPlan {
   // The scratch is one buffer per (device, n): a call that uses it waits (on the device) for the previous such
   // call, whatever stream that ran on. `done` is recorded behind the last sweep of every call.
   hipEvent_t done = nullptr;
-  hipStream_t last_stream = nullptr;
   bool used = false;
 };
 
@@ -88,19 +88,31 @@ struct ExecOpts {
   unsigned long long workspace_bytes = 0;
 };
 
-std::mutex g_mu;
+// Readers (every call that looks a plan up and launches with its tables) hold the lock shared, across the launch;
+// writers (initialize, finalize, users of the per-plan scratch state, the filter-layout tags) hold it exclusively.
+// A finalize therefore never frees a table between a reader's look-up and its launch, and it drains the device
+// before freeing what queued kernels still read.
+std::shared_mutex g_mu;
+using WriteLock = std::unique_lock<std::shared_mutex>;
+using ReadLock = std::shared_lock<std::shared_mutex>;
 std::map<std::tuple<int, int, int>, DevicePlan> g_plans;  // (device, dtype, n)
 std::map<std::tuple<int, int>, BigPlan> g_big;             // (device, n), fp32
 std::atomic<int> g_sync{0};                                // "sync": block after every launch like the reference
 
 // Which register order each permuted filter buffer was last written in (tfft_conv_filter_layout), newest last.
 struct ConvLayoutTag {
-  int device;
-  const void* ptr;
+  int device, dtype;
+  const char *begin, *end;  // the bytes the layout call wrote
   int layout_id;
 };
 std::vector<ConvLayoutTag> g_conv_tags;
 constexpr size_t kMaxConvTags = 256;
+
+// Drops every tag that overlaps [lo, hi) on `device`. g_mu must be held exclusively.
+void forget_conv_layout(int device, const char* lo, const char* hi) {
+  for (auto it = g_conv_tags.begin(); it != g_conv_tags.end();)
+    it = (it->device == device && lo < it->end && it->begin < hi) ? g_conv_tags.erase(it) : it + 1;
+}
 
 std::map<int, float4*> g_static_scratch_addr;  // device -> address of that device's copy of g_static_scratch
 
@@ -264,7 +276,7 @@ static int initialize_big(int n) {
   if (!factor_big(ilog2(n), &nf, f)) return fail(TFFT_ERR_UNSUPPORTED, "tfft_initialize: no multi-pass plan for n=%d", n);
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_mu);
+  WriteLock lock(g_mu);
   auto key = std::make_tuple(dev, n);
   if (g_big.count(key)) return TFFT_OK;
   BigPlan p;
@@ -310,7 +322,7 @@ int tfft_initialize(int dtype, int n) {
     return fail(TFFT_ERR_UNSUPPORTED, "tfft_initialize: no kernel for %s n=%d", dtype_name(dtype), n);
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_mu);
+  WriteLock lock(g_mu);
   auto key = std::make_tuple(dev, dtype, n);
   if (g_plans.count(key)) return TFFT_OK;
 
@@ -350,10 +362,27 @@ int tfft_initialize(int dtype, int n) {
 }
 
 int tfft_finalize(int dtype) {
-  std::lock_guard<std::mutex> lock(g_mu);
+  WriteLock lock(g_mu);
   int rc = TFFT_OK;
   int cur = 0;
   (void)hipGetDevice(&cur);
+  // Kernels already queued may still read the tables: wait for every device that holds one before freeing. (No
+  // reader is between its look-up and its launch: they hold the lock shared across both.)
+  {
+    std::vector<int> devices;
+    for (auto& kv : g_plans)
+      if (std::get<1>(kv.first) == dtype) devices.push_back(std::get<0>(kv.first));
+    if (dtype == TFFT_F32)
+      for (auto& kv : g_big) devices.push_back(std::get<0>(kv.first));
+    std::sort(devices.begin(), devices.end());
+    devices.erase(std::unique(devices.begin(), devices.end()), devices.end());
+    for (int d : devices) {
+      (void)hipSetDevice(d);
+      if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();  // e.g. a capture in progress: the caller's to end
+    }
+  }
+  for (auto it = g_conv_tags.begin(); it != g_conv_tags.end();)
+    it = it->dtype == dtype ? g_conv_tags.erase(it) : it + 1;
   for (auto it = g_plans.begin(); it != g_plans.end();) {
     if (std::get<1>(it->first) == dtype) {
       (void)hipSetDevice(std::get<0>(it->first));
@@ -404,7 +433,7 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info) {
   info->blocks_per_cu = 0;
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
-    std::lock_guard<std::mutex> lock(g_mu);
+    ReadLock lock(g_mu);
     auto it = g_plans.find(std::make_tuple(dev, dtype, n));
     if (it != g_plans.end()) info->blocks_per_cu = it->second.blocks_per_cu[0];
   }
@@ -415,7 +444,7 @@ int tfft_get_twiddle_table(int dtype, int n, const void** d_table) {
   if (!d_table) return fail(TFFT_ERR_INVALID, "tfft_get_twiddle_table: null result pointer");
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_mu);
+  ReadLock lock(g_mu);
   auto it = g_plans.find(std::make_tuple(dev, dtype, n));
   if (it == g_plans.end())
     return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_get_twiddle_table: call tfft_initialize(%s, %d) on device %d first",
@@ -526,19 +555,15 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
     if (opt.workspace_bytes < per)
       return fail(TFFT_ERR_INVALID, "tfft_exec_c2c_opt: workspace of %llu bytes, n=%d needs at least %llu",
                   opt.workspace_bytes, n, per);
-    BigPlan p;
-    {
-      std::lock_guard<std::mutex> lock(g_mu);
-      auto it = g_big.find(std::make_tuple(dev, n));
-      if (it == g_big.end())
-        return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
-      p = it->second;
-    }
-    return enqueue_big(p, n, forward != 0, d_in, d_out, batch, static_cast<float4*>(opt.workspace),
+    ReadLock lock(g_mu);
+    auto it = g_big.find(std::make_tuple(dev, n));
+    if (it == g_big.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
+    return enqueue_big(it->second, n, forward != 0, d_in, d_out, batch, static_cast<float4*>(opt.workspace),
                        (long long)(opt.workspace_bytes / per), opt.xcd_run_log2, s);
   }
   // library-owned scratch: enqueue under the lock, behind the previous user of the scratch
-  std::lock_guard<std::mutex> lock(g_mu);
+  WriteLock lock(g_mu);
   auto it = g_big.find(std::make_tuple(dev, n));
   if (it == g_big.end())
     return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
@@ -552,13 +577,14 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
     capture = hipStreamCaptureStatusNone;
   }
   const bool eager = capture == hipStreamCaptureStatusNone;
-  if (eager && p.used && p.last_stream != s) TFFT_HIP(hipStreamWaitEvent(s, p.done, 0));
+  // always behind the previous user, also on "the same" stream: a handle can be that of a destroyed and re-created
+  // stream, and a wait on the stream the event was recorded on costs nothing
+  if (eager && p.used) TFFT_HIP(hipStreamWaitEvent(s, p.done, 0));
   const int rc = enqueue_big(p, n, forward != 0, d_in, d_out, batch, p.work, p.work_batch, opt.xcd_run_log2, s);
   if (eager) {
     // recorded even after a failed sweep: whatever was enqueued still uses the scratch
     TFFT_HIP(hipEventRecord(p.done, s));
     p.used = true;
-    p.last_stream = s;
   }
   return rc;
 }
@@ -567,21 +593,18 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
 // (0 default, 1 and 2 the measurement builds, >= 3 the alternative plans).
 static int exec_small(const char* who, int dtype, int n, int forward, int kernel_id, const void* d_in, void* d_out,
                       long long batch, hipStream_t s, const ExecOpts& opt) {
-  DevicePlan plan;
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
-    if (it == g_plans.end()) {
-      tfft::KernelEntry probe;
-      if (!lookup(dtype, n, forward != 0, 0, &probe))
-        return fail(TFFT_ERR_UNSUPPORTED, "%s: no kernel for %s n=%d", who, dtype_name(dtype), n);
-      return fail(TFFT_ERR_NOT_INITIALIZED, "%s: call tfft_initialize(%s, %d) on device %d first", who,
-                  dtype_name(dtype), n, dev);
-    }
-    plan = it->second;
+  ReadLock lock(g_mu);  // held until the kernel that reads the plan's table is enqueued
+  auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+  if (it == g_plans.end()) {
+    tfft::KernelEntry probe;
+    if (!lookup(dtype, n, forward != 0, 0, &probe))
+      return fail(TFFT_ERR_UNSUPPORTED, "%s: no kernel for %s n=%d", who, dtype_name(dtype), n);
+    return fail(TFFT_ERR_NOT_INITIALIZED, "%s: call tfft_initialize(%s, %d) on device %d first", who,
+                dtype_name(dtype), n, dev);
   }
+  const DevicePlan& plan = it->second;
   tfft::KernelEntry e;
   if (!lookup(dtype, n, forward != 0, kernel_id, &e))
     return fail(TFFT_ERR_UNSUPPORTED, "%s: no kernel for %s n=%d forward=%d plan=%d", who, dtype_name(dtype), n, forward,
@@ -596,6 +619,15 @@ static int exec_small(const char* who, int dtype, int n, int forward, int kernel
     if (lookup(dtype, n, forward != 0, 3 /* the alternative plan */, &small)) e = small;
   }
   const long long nchunks = (batch + e.tpb - 1) / e.tpb;
+  if (e.one_workgroup_per_transform) {
+    // these kernels take their transform from blockIdx alone: no resident form, and the grid is the batch
+    if (opt.grid_blocks_per_cu > 0 || opt.grid_blocks > 0)
+      return fail(TFFT_ERR_UNSUPPORTED, "%s: the kernel of %s n=%d runs one workgroup per transform and has no resident "
+                  "grid (grid_blocks, grid_blocks_per_cu)", who, dtype_name(dtype), n);
+    if (batch > 0x7fffffffLL)
+      return fail(TFFT_ERR_INVALID, "%s: batch %lld exceeds one launch (2^31 - 1 transforms) for %s n=%d", who, batch,
+                  dtype_name(dtype), n);
+  }
   // Default: one workgroup per chunk. The hardware dispatcher then hands out chunks in address
   // order as workgroups retire, which streams HBM measurably better than a resident grid walking
   // the batch with a stride; grid_blocks_per_cu selects the resident (persistent) form instead.
@@ -657,18 +689,17 @@ int tfft_exec_c2c_static(int dtype, int n, int forward, const void* d_in, void* 
                 "tfft_exec_c2c or a caller workspace", n, kStaticScratchPoints);
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  BigPlan p;
   float4* scratch = nullptr;
   {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_big.find(std::make_tuple(dev, n));
-    if (it == g_big.end())
-      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c_static: call tfft_initialize(fp32, %d) on device %d first", n, dev);
-    p = it->second;
+    WriteLock lock(g_mu);  // the address table is filled on first use per device (tfft_initialize does that)
     if (int rc = static_scratch_for(dev, &scratch)) return rc;
   }
+  ReadLock lock(g_mu);
+  auto it = g_big.find(std::make_tuple(dev, n));
+  if (it == g_big.end())
+    return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c_static: call tfft_initialize(fp32, %d) on device %d first", n, dev);
   // Every sweep writes the part of the scratch it later reads, so nothing needs clearing between calls.
-  if (int rc = enqueue_big(p, n, forward != 0, d_in, d_out, batch, scratch, kStaticScratchPoints / n, -1, s)) return rc;
+  if (int rc = enqueue_big(it->second, n, forward != 0, d_in, d_out, batch, scratch, kStaticScratchPoints / n, -1, s)) return rc;
   return finish_launch(s);
 }
 
@@ -703,15 +734,12 @@ int tfft_bench_onchip_repeats(int dtype, int n, int repeats, const void* d_in, v
     return fail(TFFT_ERR_UNSUPPORTED, "tfft_bench_onchip_repeats: the 16-bit matrix-core kernels only");
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  DevicePlan plan;
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
-    if (it == g_plans.end())
-      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_bench_onchip_repeats: call tfft_initialize(%s, %d) on device %d first",
-                  dtype_name(dtype), n, dev);
-    plan = it->second;
-  }
+  ReadLock lock(g_mu);
+  auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+  if (it == g_plans.end())
+    return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_bench_onchip_repeats: call tfft_initialize(%s, %d) on device %d first",
+                dtype_name(dtype), n, dev);
+  const DevicePlan& plan = it->second;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool ok = dtype == TFFT_F16 ? tfft::launch_repeat_f16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, 3u, s)
                                     : tfft::launch_repeat_bf16(n, d_in, d_out, plan.tw, batch, (unsigned)repeats, 3u, s);
@@ -723,15 +751,12 @@ int tfft_bench_onchip_repeats(int dtype, int n, int repeats, const void* d_in, v
 static int exec_half_traffic(int dtype, int n, int pattern, const void* d_in, void* d_out, long long batch, hipStream_t s) {
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  DevicePlan plan;
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
-    if (it == g_plans.end())
-      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_bench_access_pattern: call tfft_initialize(%s, %d) on device %d first",
-                  dtype_name(dtype), n, dev);
-    plan = it->second;
-  }
+  ReadLock lock(g_mu);
+  auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+  if (it == g_plans.end())
+    return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_bench_access_pattern: call tfft_initialize(%s, %d) on device %d first",
+                dtype_name(dtype), n, dev);
+  const DevicePlan& plan = it->second;
   const unsigned io_mask = pattern == 3 ? 1u : 2u;
   const bool ok = dtype == TFFT_F16 ? tfft::launch_repeat_f16(n, d_in, d_out, plan.tw, batch, 1u, io_mask, s)
                                     : tfft::launch_repeat_bf16(n, d_in, d_out, plan.tw, batch, 1u, io_mask, s);
@@ -764,15 +789,23 @@ int tfft_conv_filter_layout_opt(int dtype, int n, const void* d_h_freq, void* d_
   TFFT_HIP(hipGetLastError());
   {
     // remember the order this buffer now holds, for the check in tfft_conv_exec
-    std::lock_guard<std::mutex> lock(g_mu);
-    for (auto it = g_conv_tags.begin(); it != g_conv_tags.end(); ++it)
-      if (it->device == dev && it->ptr == d_h_perm) {
-        g_conv_tags.erase(it);
-        break;
-      }
+    WriteLock lock(g_mu);
+    const char* lo = static_cast<const char*>(d_h_perm);
+    const char* hi = lo + (size_t)D * n * (dtype == TFFT_F32 ? 8 : 4);
+    forget_conv_layout(dev, lo, hi);  // whatever these bytes held before is overwritten
     if (g_conv_tags.size() >= kMaxConvTags) g_conv_tags.erase(g_conv_tags.begin());
-    g_conv_tags.push_back(ConvLayoutTag{dev, d_h_perm, e.layout_id});
+    g_conv_tags.push_back(ConvLayoutTag{dev, dtype, lo, hi, e.layout_id});
   }
+  return TFFT_OK;
+}
+
+int tfft_conv_forget_layout(const void* d_buffer, unsigned long long bytes) {
+  if (!d_buffer) return fail(TFFT_ERR_INVALID, "tfft_conv_forget_layout: null pointer");
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  WriteLock lock(g_mu);
+  const char* lo = static_cast<const char*>(d_buffer);
+  forget_conv_layout(dev, lo, lo + (bytes ? bytes : 1));
   return TFFT_OK;
 }
 
@@ -794,21 +827,21 @@ int tfft_conv_exec_opt(int dtype, int n, int kind, const void* d_x, const void* 
     return fail(TFFT_ERR_INVALID, "tfft_conv_exec: buffers must be 16-byte aligned");
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  DevicePlan plan;
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
-    if (it == g_plans.end())
-      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_exec: call tfft_initialize(%s, %d) on device %d first",
-                  dtype_name(dtype), n, dev);
-    plan = it->second;
-    // a filter buffer this library permuted for the other kernel's register order would convolve silently wrong
-    for (const ConvLayoutTag& t : g_conv_tags)
-      if (t.device == dev && t.ptr == d_h_perm && t.layout_id != e.layout_id)
-        return fail(TFFT_ERR_INVALID,
-                    "tfft_conv_exec: d_h_perm was written by tfft_conv_filter_layout for the other kernel "
-                    "(plan 0 and plan 3 use different filter orders); permute it again with this call's plan");
-  }
+  ReadLock lock(g_mu);
+  auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+  if (it == g_plans.end())
+    return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_exec: call tfft_initialize(%s, %d) on device %d first",
+                dtype_name(dtype), n, dev);
+  const DevicePlan& plan = it->second;
+  // a filter buffer this library permuted for the other kernel's register order would convolve silently wrong;
+  // the D spectra this call reads are matched against the byte ranges the layout calls wrote
+  const char* h_lo = static_cast<const char*>(d_h_perm);
+  const char* h_hi = h_lo + (size_t)D * n * (dtype == TFFT_F32 ? 8 : 4);
+  for (const ConvLayoutTag& t : g_conv_tags)
+    if (t.device == dev && h_lo < t.end && t.begin < h_hi && t.layout_id != e.layout_id)
+      return fail(TFFT_ERR_INVALID,
+                  "tfft_conv_exec: d_h_perm was written by tfft_conv_filter_layout for the other kernel "
+                  "(plan 0 and plan 3 use different filter orders); permute it again with this call's plan");
   e.launch(d_x, d_h_perm, d_y, plan.tw, B, D, (int)opt.grid_blocks_per_cu, static_cast<hipStream_t>(stream));
   return finish_launch(static_cast<hipStream_t>(stream));
 }
@@ -832,15 +865,12 @@ int tfft_conv_tiles_exec(int dtype, int n, const void* d_in, const void* d_hf, v
     return fail(TFFT_ERR_INVALID, "tfft_conv_tiles_exec: too many tiles for one launch");
   int dev = 0;
   TFFT_HIP(hipGetDevice(&dev));
-  DevicePlan plan;
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
-    if (it == g_plans.end())
-      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_tiles_exec: call tfft_initialize(%s, %d) on device %d first",
-                  dtype_name(dtype), n, dev);
-    plan = it->second;
-  }
+  ReadLock lock(g_mu);
+  auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+  if (it == g_plans.end())
+    return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_tiles_exec: call tfft_initialize(%s, %d) on device %d first",
+                dtype_name(dtype), n, dev);
+  const DevicePlan& plan = it->second;
   e.launch(d_in, d_hf, d_out, plan.tw, input_len, output_len, valid, static_cast<hipStream_t>(stream));
   return finish_launch(static_cast<hipStream_t>(stream));
 }

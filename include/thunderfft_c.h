@@ -33,11 +33,16 @@ enum {
 /* Replaces thunderfft::ThunderFFTInitialize<T>(int N) (thunderfft.cuh:39-40; body
  * detail/thunderfft_impl_twiddle.cuh:261-311): builds the twiddle table of length n in fp64
  * on the host, rounds once to fp32 and uploads it to the current device. Tables are cached
- * per (device, dtype, n); calling again with the same arguments is a no-op. Allocates. */
+ * per (device, dtype, n); calling again with the same arguments is a no-op. Allocates.
+ * Thread safety: every entry point may be called from any thread. Calls that launch hold the plan cache shared
+ * from their look-up to their launch; tfft_initialize and tfft_finalize hold it exclusively. */
 int tfft_initialize(int dtype, int n);
 
 /* Replaces thunderfft::ThunderFFTFinalize<T>() (thunderfft.cuh:43-44; body
- * thunderfft_impl_twiddle.cuh:342-349): frees every table of `dtype` on every device. */
+ * thunderfft_impl_twiddle.cuh:342-349): frees every table of `dtype` on every device. It first waits for the
+ * work already queued on those devices (kernels launched earlier may still read the tables), so it may run
+ * concurrently with tfft_exec_* calls of other threads: each of those either launched before the tables went away
+ * or returns TFFT_ERR_NOT_INITIALIZED. Do not call it while a stream of an affected device is being captured. */
 int tfft_finalize(int dtype);
 
 /* Replaces thunderfft::ThunderFFT_global<T, N, forward>(d_input, d_output, batch, stream)
@@ -49,7 +54,14 @@ int tfft_finalize(int dtype);
  * tfft_initialize allocated (four-step; the reference has no transform beyond 4096). That scratch
  * is one buffer per (device, n): multi-pass calls that share it are ordered on the device by an
  * event, so calls from several streams or threads stay correct but do not overlap; pass a
- * workspace of your own (tfft_exec_c2c_opt) for calls that should. */
+ * workspace of your own (tfft_exec_c2c_opt) for calls that should. A multi-pass call made under stream capture
+ * is ordered inside its graph only: replays of that graph are not ordered against other users of the
+ * library-owned scratch (eager calls, other graphs) -- captured callers use tfft_exec_c2c_static or a workspace.
+ * Non-finite inputs: a NaN or infinity stays inside its own transform, with one exception: 16-bit storage at
+ * 512 <= n <= 2048 (default plan) runs 2 ... 8 transforms through one matrix product per 4096-point tile, with
+ * explicit zeros between them, so a non-finite value also turns the other transforms of its tile (the 4096 / n
+ * consecutive transforms starting at a multiple of 4096 / n) non-finite. tfft_exec_options.plan = 3 (the fp32-VALU
+ * kernels) keeps every transform independent. */
 int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
                   void* stream);
 
@@ -240,6 +252,13 @@ int tfft_conv_exec_opt(int dtype, int n, int kind, const void* d_x, const void* 
                        void* stream, const tfft_exec_options* opt);
 int tfft_conv_filter_layout_opt(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream,
                                 const tfft_exec_options* opt);
+
+/* The order check above knows only what tfft_conv_filter_layout(_opt) wrote: it keeps the byte range of each of
+ * its last 256 outputs per process and compares any d_h_perm that overlaps one. A range whose contents the caller
+ * replaced by other means (a copy of a saved buffer, an allocator handing the address out again) is stale:
+ * tfft_conv_forget_layout drops what is recorded for [d_buffer, d_buffer + bytes) on the current device (bytes = 0:
+ * any record that contains d_buffer). tfft_finalize(dtype) drops all records of dtype. No reference counterpart. */
+int tfft_conv_forget_layout(const void* d_buffer, unsigned long long bytes);
 
 /* Overlap-save tiled convolution with transforms of length n: for every tile t,
  *   out[t*valid + j] = IDFT_n( DFT_n(in[t*valid .. t*valid + n)) * hf )[j],   j < valid, t*valid + j < output_len,

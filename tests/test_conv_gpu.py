@@ -182,6 +182,35 @@ def test_valu_plan_and_filter_layout_mismatch(oracle_mod):
         assert e.value.code == 3
 
 
+def test_filter_layout_records_are_ranges_and_can_be_dropped():
+    """The order check matches byte ranges (a pointer into a recorded buffer is still checked), a range refilled
+    by the caller is released with tfft_conv_forget_layout, and tfft_finalize drops the records of its dtype."""
+    B, D, K = 1, 4, 5
+    x = torch.rand(B, D, N, device="cuda").to(torch.float16)
+    h = (torch.rand(D, K, 2, device="cuda") / N).to(torch.float16)
+    hp_mfma = conv.filter_spectra(h, N)
+    hp_valu = conv.filter_spectra(h, N, options={"plan": 3})
+    # filters 2 and 3 of the matrix-core buffer, through a pointer inside it
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        conv.fft_conv(x[:, 2:].contiguous(), hp_mfma[2:], N, conv.CONV_REAL_IN_OUT, options={"plan": 3})
+    assert e.value.code == 3
+    # the caller overwrites that buffer with VALU-order spectra: stale record until it is dropped
+    saved = hp_valu.clone()
+    hp_mfma.copy_(saved)
+    with pytest.raises(fft_amd.ThunderFFTError):
+        conv.fft_conv(x, hp_mfma, N, conv.CONV_REAL_IN_OUT, options={"plan": 3})
+    conv.forget_layout(hp_mfma)
+    y = conv.fft_conv(x, hp_mfma, N, conv.CONV_REAL_IN_OUT, options={"plan": 3})
+    want = conv.fft_conv(x, hp_valu, N, conv.CONV_REAL_IN_OUT, options={"plan": 3})
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    # finalize forgets: the (now wrong) pairing is no longer rejected, the library only tracks what it wrote
+    fft_amd.ThunderFFTFinalize("fp16")
+    fft_amd.ThunderFFTInitialize("fp16", N)
+    conv.fft_conv(x, hp_valu, N, conv.CONV_REAL_IN_OUT)
+    torch.cuda.synchronize()
+
+
 def test_errors():
     x = torch.zeros(1, 1, 1024, 2, device="cuda")
     with pytest.raises(fft_amd.ThunderFFTError) as e:

@@ -17,7 +17,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from fft_amd import synth  # noqa: E402
-from fft_amd.distributed import DistributedFFT, NumpyOps, run_virtual, split_n  # noqa: E402
+from fft_amd.distributed import DistributedFFT, run_virtual, split_n  # noqa: E402
+from dist_reference import NumpyOps  # noqa: E402
 
 
 def oracle_rows(x, forward):

@@ -43,6 +43,36 @@ def test_static_scratch_matches_the_allocating_path(oracle_mod):
         assert oracle_mod.rel_l2(ys[..., 0] + 1j * ys[..., 1], oracle_mod.fft(xs[..., 0] + 1j * xs[..., 1])) <= 3e-6
 
 
+def test_static_entry_allocates_nothing():
+    """The property the entry point exists for: across calls made after tfft_initialize the device's free memory
+    does not move (nothing allocated, nothing freed), and the library-owned scratch of the allocating path is not
+    touched: with that scratch poisoned by NaNs the static results are still exact."""
+    n, batch = 1 << 18, 6
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    want = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x, want, batch, n, True)
+    got = torch.empty_like(x)
+    exec_static(x, got, batch, n, True)  # first use on this device done: addresses resolved, code loaded
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    for forward in (True, False, True):
+        exec_static(x, got, batch, n, forward)
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before, (free_before, free_after)
+    assert torch.equal(got, want)
+    # The allocating path leaves its intermediate sweeps in the plan's own scratch; the static path must not read it.
+    # Run the allocating path on NaN input (its scratch now holds NaNs), then the static path on real input.
+    poison = torch.full_like(x, float("nan"))
+    fft_amd.ThunderFFT_global(poison, torch.empty_like(x), batch, n, True)
+    got.zero_()
+    exec_static(x, got, batch, n, True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_static_in_place_and_full_scratch():
     n, batch = 1 << 20, 2  # one transform fills the whole scratch
     g = torch.Generator(device="cuda").manual_seed(7)

@@ -1,4 +1,4 @@
-"""Mean %HBM per (N, L) from tools/gpu_xcd.sh logs. Usage: python tools/xcd_table.py gpurun_out/xcd*.log"""
+"""Mean %HBM per (N, L) from the logs of an XCD run-length sweep (tools/gpu_ab.sh with XCDS="0 2 4 6"). Usage: python tools/xcd_table.py gpurun_out/xcd*.log"""
 import collections
 import re
 import sys
