@@ -19,8 +19,8 @@ dimension shards trivially and no collective touches the data path:
 
   value        whole-job GFLOP/s with the 5 N log2 N convention, inputs resident in HBM
   roofline     algorithmic HBM bytes (16 B per point: one read + one write) per launch divided
-               by the mean launch duration measured with events on the launch stream, against
-               8 TB/s; `traffic` is the PMC-measured HBM bytes per launch recorded under
+               by the mean launch duration -- one event pair on the launch stream around the K timed
+               launches, elapsed / K -- against 8 TB/s; `traffic` is the PMC-measured HBM bytes per launch recorded under
                profiles/ for this same kernel (null if no such record matches). Multi-pass lengths
                (n > 16384) also report the per-sweep model: every sweep reads and writes all points.
   cpu_baseline the CPU FFT (scipy/pocketfft on complex64, one worker per host core of the box's share, the
@@ -133,7 +133,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=("fp32", "fp16", "bf16"), default="fp32",
                     help="storage type; fp32 is the headline configuration, fp16 / bf16 the 16-bit one (8 B per point)")
-    ap.add_argument("--out-of-place", action="store_true", help="force x -> y for 16-bit storage (default there: in place)")
+    ap.add_argument("--out-of-place", action="store_true", help="x -> y: the default (kept so that older command lines still parse)")
+    ap.add_argument("--event-per-step", action="store_true",
+                    help="bracket every launch with its own event pair instead of one pair around the timed region")
     ap.add_argument("--stub-step", action="store_true",
                     help="launcher self-test without a GPU: gloo ranks, a sleep as the step; the line says data=stub")
     args = ap.parse_args(argv)
@@ -141,10 +143,10 @@ def parse_args(argv=None):
         ap.error("--gpus must be >= 1")
     if args.batch <= 0:
         args.batch = max(1, POINTS // args.n)
-    # fp32: x -> y (the call shape of the reference's fft1d sample; measured equal or faster than in place).
-    # 16-bit storage: in place like the reference's bench (sample/bench/baseline/thunderfft_bench.h:124-125);
-    # writing the rows just read measured 6 points faster than a separate output stream there.
-    args.out_of_place = args.out_of_place or (args.dtype == "fp32" and not args.in_place)
+    # x -> y for every storage type (the call shape of the reference's fft1d sample, sample/fft1d/main.cu:116);
+    # --in-place is the reference bench's form (sample/bench/baseline/thunderfft_bench.h:124-125). Once the device
+    # has settled the two forms run at the same rate for all three storage types.
+    args.out_of_place = not args.in_place
     return args
 
 
@@ -236,7 +238,10 @@ def main(argv=None):
         def step():
             time.sleep(0.002)
 
-        def keep_finite():
+        def rescale_due():
+            return False
+
+        def rescale():
             pass
 
         def sync():
@@ -267,32 +272,60 @@ def main(argv=None):
 
         done = 0
 
-        def keep_finite():
-            # only reached on runs longer than RESCALE_EVERY passes; outside the event-timed launches
+        def rescale_due():
+            # in place only, on runs longer than RESCALE_EVERY passes
             nonlocal done
             done += 1
-            if not args.out_of_place and done % RESCALE_EVERY == 0:
-                x.mul_(float(n) ** (-RESCALE_EVERY / 2.0))
+            return not args.out_of_place and done % RESCALE_EVERY == 0
+
+        def rescale():
+            x.mul_(float(n) ** (-RESCALE_EVERY / 2.0))
 
         def sync():
             torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
-        keep_finite()
+        if rescale_due():
+            rescale()
     sharding.barrier(dist, sync)
 
-    if not stub:
-        starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-        ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # Events on the launch stream bracket the timed region: the K launches run back to back, as a caller's would,
+    # and the mean launch duration is the region's elapsed time / K (launch gaps included). An in-place run longer
+    # than RESCALE_EVERY passes closes the pair around each rescaling of its data, so that the event time holds
+    # transform launches only (the wall clock, and with it `value`, includes those extra kernels).
+    # --event-per-step brackets every launch with its own pair instead; the extra packets between launches cost
+    # each launch 10-20 us.
+    per_step = args.event_per_step and not stub
+    starts, ends = [], []
+
+    def open_pair():
+        if not stub:
+            starts.append(torch.cuda.Event(enable_timing=True))
+            starts[-1].record(stream)
+
+    def close_pair():
+        if not stub:
+            ends.append(torch.cuda.Event(enable_timing=True))
+            ends[-1].record(stream)
+
     t0 = time.perf_counter()
+    if not per_step:
+        open_pair()
     for i in range(args.steps):
-        if not stub:
-            starts[i].record(stream)
+        if per_step:
+            open_pair()
         step()
-        if not stub:
-            ends[i].record(stream)
-        keep_finite()
+        if per_step:
+            close_pair()
+        if rescale_due():
+            if not per_step:
+                close_pair()
+            rescale()
+            if not per_step:
+                open_pair()
+    if not per_step:
+        close_pair()
     sharding.barrier(dist, sync)
     wall = time.perf_counter() - t0
 
@@ -365,6 +398,8 @@ def main(argv=None):
                 "kernel": label,
                 "kernel_signature": signature,
                 "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_from": ("one HIP event pair per launch" if args.event_per_step
+                                   else f"one HIP event pair around the {args.steps} timed launches / {args.steps}"),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 # fraction of peak the kernel's own load/store pattern reaches with the arithmetic compiled out
                 "load_store_only_frac": (round(bytes_per_launch / (shape_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS, 4)

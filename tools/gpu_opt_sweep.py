@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--points", type=int, default=1 << 28)
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--in-place", action="store_true")
+    ap.add_argument("--burst", type=int, default=1,
+                    help="launches per timed group, back to back with no host synchronisation in between (sustained "
+                         "load); 1 = isolated launches")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     n, batch = a.n, a.points // a.n
@@ -35,18 +38,23 @@ def main():
         variants.append((name, opts))
     stream = torch.cuda.current_stream()
     times = {name: [] for name, _ in variants}
+    # in place: restore the input before every group (an unnormalised transform grows its data); bursts run on
+    # whatever the previous launch left, pre-scaled so that the last pass stays finite
     keep = x.clone() if a.in_place else None
+    if keep is not None and a.burst > 1:
+        keep.mul_(float(n) ** (-a.burst / 2.0))
     for r in range(a.rounds + 2):
         for name, opts in variants:
             if keep is not None:
                 x.copy_(keep)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(stream)
-            fft_amd.ThunderFFT_global(x, y, batch, n, True, stream, options=opts or None)
+            for _ in range(a.burst):
+                fft_amd.ThunderFFT_global(x, y, batch, n, True, stream, options=opts or None)
             e.record(stream)
             torch.cuda.synchronize()
             if r >= 2:
-                times[name].append(s.elapsed_time(e))
+                times[name].append(s.elapsed_time(e) / a.burst)
     per_point = 16 if a.dtype == "fp32" else 8
     for name, _ in variants:
         t = times[name]
