@@ -288,13 +288,34 @@ void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, 
   }
 }
 
+// One workgroup per run of RUN work items of one filter (fft_conv_mfma4096_run_kernel); per_cu is not used.
+template <int KIND, int RUN>
+void launch_conv_mfma_run(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int per_cu,
+                          hipStream_t stream) {
+  (void)per_cu;
+  const unsigned nb = (KIND == kConvMfmaRealPair) ? ((unsigned)B + 1u) / 2u : (unsigned)B;
+  const unsigned runs = (nb + RUN - 1) / RUN;
+  fft_conv_mfma4096_run_kernel<KIND, RUN><<<dim3(runs * (unsigned)D), dim3(256), 0, stream>>>(
+      x, static_cast<const u32x4_t*>(hp), y, tw, B, D);
+}
+
+template <int RUN>
+bool conv_mfma_run_entry(int kind, ConvEntry* out) {
+  switch (kind) {
+    case kConvComplex: out->launch = &launch_conv_mfma_run<kConvMfmaComplex, RUN>; return true;
+    case kConvRealIn: out->launch = &launch_conv_mfma_run<kConvMfmaRealIn, RUN>; return true;
+    case kConvRealInOut: out->launch = &launch_conv_mfma_run<kConvMfmaRealPair, RUN>; return true;
+    default: return false;
+  }
+}
+
 void launch_layout_mfma(const void* h, void* hp, int D, hipStream_t stream) {
   conv_mfma4096_filter_layout_kernel<0><<<dim3((unsigned)D), dim3(256), 0, stream>>>(static_cast<const unsigned*>(h),
                                                                                    static_cast<u32x4_t*>(hp), D);
 }
 
 bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
-  if (n != 4096 || (plan != 0 && plan != 3)) return false;
+  if (n != 4096 || (plan != 0 && plan != 3 && !(dtype == TFFT_F16 && plan >= 5 && plan <= 7))) return false;
   out->layout_id = kConvLayoutValu;
   if (dtype == TFFT_F16 && plan != 3) {
     // fp16 storage: both transforms on the matrix cores (fft_conv_mfma.hpp)
@@ -304,6 +325,9 @@ bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
     out->lds_bytes = 4 * (Mfma4096::OUT_IMG + Mfma4096::IMG);
     out->layout = &launch_layout_mfma;
     out->layout_id = kConvLayoutMfma;
+    if (plan == 5) return conv_mfma_run_entry<4>(kind, out);
+    if (plan == 6) return conv_mfma_run_entry<2>(kind, out);
+    if (plan == 7) return conv_mfma_run_entry<8>(kind, out);
     switch (kind) {
       case kConvComplex: out->launch = &launch_conv_mfma<kConvMfmaComplex>; return true;
       case kConvRealIn: out->launch = &launch_conv_mfma<kConvMfmaRealIn>; return true;

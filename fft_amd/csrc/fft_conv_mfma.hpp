@@ -326,4 +326,173 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
   }
 }
 
+// The same convolution with one workgroup per RUN consecutive work items of one filter. A workgroup's life is then
+// several items long, and while one item is in its six passes the rows of the next are already on their way: the
+// one-shot kernel above has every workgroup wait for its rows, run its passes and store, with only the other
+// workgroups of the CU to fill those waits, and measures close to the SUM of its HBM time and its on-chip time.
+// To stay within 128 VGPRs (four workgroups per CU) while holding the next item's rows:
+//   * the filter spectrum of the run is loaded once and kept (items of a run share the filter);
+//   * the start / step values of the incremental pass-1 twiddles are fetched where they are used, per item and
+//     direction, from the L2-resident table (an opaque zero offset keeps the loads inside the item loop);
+//   * the inverse matrix fragments are the forward ones with the sine halves' signs flipped (8 v_xor per use).
+template <int KIND, int RUN>
+__global__ __launch_bounds__(256, 4) void fft_conv_mfma4096_run_kernel(const void* xv, const u32x4_t* __restrict__ hp,
+                                                                       void* yv,  // xv and yv may alias
+                                                                       const float2* __restrict__ tw, int B, int D) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + Mfma4096::IMG];
+  unsigned* const img_a = lds;
+  unsigned* const img_b = lds + Mfma4096::OUT_IMG;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+
+  // workgroup -> (filter d, items bq0 .. bq1 - 1 of that filter)
+  const int nb = (KIND == kConvMfmaRealPair) ? (B + 1) >> 1 : B;
+  const int runs = (nb + RUN - 1) / RUN;
+  const int d = blockIdx.x / runs;
+  if (d >= D) return;
+  const int bq0 = (blockIdx.x - d * runs) * RUN;
+  const int bq1 = min(nb, bq0 + RUN);
+
+  u32x4_t rows[4];
+  auto request_rows = [&](int bq) {
+    const int b0 = (KIND == kConvMfmaRealPair) ? 2 * bq : bq;
+    const long long s0 = (long long)b0 * D + d;
+    if constexpr (KIND == kConvMfmaComplex) {
+      const u32x4_t* src = static_cast<const u32x4_t*>(xv) + s0 * 1024 + 16 * w + i;
+#pragma unroll
+      for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
+    } else {
+      const bool two = (KIND == kConvMfmaRealPair) && (b0 + 1 < B);
+      const u32x2_t* src0 = static_cast<const u32x2_t*>(xv) + s0 * 1024 + 16 * w + i;
+      const u32x2_t* src1 = src0 + (long long)D * 1024;
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        const u32x2_t a = __builtin_nontemporal_load(src0 + (4 * G + g) * 64);
+        u32x2_t c = {0u, 0u};
+        if (two) c = __builtin_nontemporal_load(src1 + (4 * G + g) * 64);
+        rows[G] = u32x4_t{(a.x & 0xffffu) | (c.x << 16), (a.x >> 16) | (c.x & 0xffff0000u),
+                          (a.y & 0xffffu) | (c.y << 16), (a.y >> 16) | (c.y & 0xffff0000u)};
+      }
+    }
+  };
+  request_rows(bq0);
+
+  // ---- kept for the whole run: the filter in lane order, the forward matrix fragments, the pass-2 twiddles
+  u32x4_t hreg[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) hreg[t] = hp[(long long)d * 1024 + t * 256 + tid];
+  h2_t t2[4];
+  {
+    const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
+    const u32x4_t p = ftab[128], q = ftab[192];
+    t2[0] = pack_h2(__uint_as_float(p.x), __uint_as_float(p.y));
+    t2[1] = pack_h2(__uint_as_float(p.z), __uint_as_float(p.w));
+    t2[2] = pack_h2(__uint_as_float(q.x), __uint_as_float(q.y));
+    t2[3] = pack_h2(__uint_as_float(q.z), __uint_as_float(q.w));
+  }
+  MfmaDir<true> fwd;
+  fwd.init(tw, tid);
+  const float4* const ctab = reinterpret_cast<const float4*>(tw + ConvMfma4096::OFFSET);
+  // start / step of one column map (0: columns 64w + 4i + j, the rows from memory; 1: 16 (4w + t) + i, the chained
+  // registers), fetched through an offset the optimiser cannot see is zero
+  auto fetch_twiddles = [&](int map, c32 (&start)[4], c32 (&step)[4]) {
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const float4* tab = ctab + opaque;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 a = tab[map * 512 + h * 256 + tid];
+      const float4 p = tab[1024 + map * 8 + h * 4 + g];
+      start[2 * h] = make_float2(a.x, a.y);
+      start[2 * h + 1] = make_float2(a.z, a.w);
+      step[2 * h] = make_float2(p.x, p.y);
+      step[2 * h + 1] = make_float2(p.z, p.w);
+    }
+  };
+
+#pragma unroll 1
+  for (int bq = bq0; bq < bq1; ++bq) {
+    const int b0 = (KIND == kConvMfmaRealPair) ? 2 * bq : bq;
+    const bool two = (KIND == kConvMfmaRealPair) && (b0 + 1 < B);
+    const long long s0 = (long long)b0 * D + d, s1 = s0 + D;
+
+    // ---- forward transform
+    u32x4_t packed[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned a0 = rows[0][j], a1 = rows[1][j], a2 = rows[2][j], a3 = rows[3][j];
+      auto s = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+      a0 = s[0]; a2 = s[1];
+      s = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+      a1 = s[0]; a3 = s[1];
+      s = __builtin_amdgcn_permlane16_swap(a0, a1, false, false);
+      a0 = s[0]; a1 = s[1];
+      s = __builtin_amdgcn_permlane16_swap(a2, a3, false, false);
+      a2 = s[0]; a3 = s[1];
+      packed[j] = u32x4_t{a0, a1, a2, a3};
+    }
+    if (bq + 1 < bq1) request_rows(bq + 1);  // lands under this item's passes
+    {
+      c32 start[4], step[4];
+      fetch_twiddles(0, start, step);
+      mfma_pass1<true, false>(fwd, packed, start, step, img_a, w, g, i);
+    }
+    __syncthreads();
+    mfma_pass2<true>(fwd, t2, img_a, img_b, w, g, i);
+    __syncthreads();
+    mfma_f4 xr[4], xi[4];
+    mfma_pass3<true>(fwd, img_b, xr, xi, w, g, i);
+
+    // ---- product with the filter spectrum, rounded to fp16: the inverse's first-pass fragments
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        packed[t][r] = cmul_h2<false>(pack_h2(xr[t][r], xi[t][r]), __builtin_bit_cast(h2_t, (unsigned)hreg[t][r]));
+    }
+
+    // ---- inverse transform: the conjugate matrix = the forward rows with the signs of their sine halves flipped
+    // ((cos, sin) pairs in the real-output rows, (-sin, cos) in the imaginary-output rows)
+    MfmaDir<false> inv;
+    {
+      const u32x4_t fr = __builtin_bit_cast(u32x4_t, fwd.a_re), fi = __builtin_bit_cast(u32x4_t, fwd.a_im);
+      inv.a_re = __builtin_bit_cast(mfma_h8, fr ^ 0x80000000u);
+      inv.a_im = __builtin_bit_cast(mfma_h8, fi ^ 0x00008000u);
+    }
+    {
+      c32 start[4], step[4];
+      fetch_twiddles(1, start, step);
+      mfma_pass1<false, true>(inv, packed, start, step, img_a, w, g, i);
+    }
+    __syncthreads();
+    mfma_pass2<false>(inv, t2, img_a, img_b, w, g, i);
+    __syncthreads();
+    mfma_pass3<false>(inv, img_b, xr, xi, w, g, i);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k3 = 4 * g + r;
+        img_a[i + 16 * (4 * w + t) + 256 * k3 + 4 * k3] = pack_f16(xr[t][r], xi[t][r]);
+      }
+    }
+    __syncthreads();
+
+    // ---- natural order out
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
+      if constexpr (KIND == kConvMfmaRealPair) {
+        const u32x2_t y0 = {(v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16)};
+        const u32x2_t y1 = {(v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u)};
+        __builtin_nontemporal_store(y0, static_cast<u32x2_t*>(yv) + s0 * 1024 + tid + 256 * q);
+        if (two) __builtin_nontemporal_store(y1, static_cast<u32x2_t*>(yv) + s1 * 1024 + tid + 256 * q);
+      } else {
+        __builtin_nontemporal_store(v, static_cast<u32x4_t*>(yv) + s0 * 1024 + tid + 256 * q);
+      }
+    }
+    __syncthreads();  // the output image is read before the next item's first pass overwrites it
+  }
+}
+
 }  // namespace tfft

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 EXTRA="${BENCH_ARGS:-}"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $R/bench.py --steps 10 --no-cpu-baseline $EXTRA > $OUT/trace_stdout.log 2>&1 || { tail -5 $OUT/trace_stdout.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $R/bench.py --steps ${TRACE_STEPS:-20} --warmup ${TRACE_WARMUP:-3} --no-cpu-baseline $EXTRA > $OUT/trace_stdout.log 2>&1 || { tail -5 $OUT/trace_stdout.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/pmc_fetch_stdout.log 2>&1 || { tail -5 $OUT/pmc_fetch_stdout.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/pmc_write_stdout.log 2>&1 || { tail -5 $OUT/pmc_write_stdout.log; exit 1; }
 find $OUT -name "*.csv" | head -20

@@ -34,6 +34,10 @@ def is_fft(name):
     return "tfft::fft_" in name
 
 
+def launches_per_transform_hint(n, fft_rows):
+    return len(fft_rows) if n > 16384 else 1
+
+
 def main():
     tag = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
@@ -66,8 +70,28 @@ def main():
         steps = max(1, min(int(r["Calls"]) for r in fft_rows))
         launches_per_transform = max(1, round(total_calls / steps))
         hbm *= launches_per_transform
+    # The launches of bench.py's timed region: the last `steps` launches of the kernel in the trace (the warm-up
+    # launches come first; 16-bit kernels are still ramping up during them).
+    timed = None
+    try:
+        steps = None
+        for text in open(os.path.join(src, "trace_stdout.log")):
+            if text.startswith('{"metric"'):
+                steps = json.loads(text)["steps"]
+        trace = [r for r in csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_trace.csv")))
+                 if r["Kernel_Name"] in fft_names]
+        trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+        if steps and len(trace) >= steps * launches_per_transform_hint(n, fft_rows):
+            k = steps * launches_per_transform_hint(n, fft_rows)
+            last = trace[-k:]
+            dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
+            span = int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
+            timed = {"launches": k, "mean_kernel_ns": sum(dur) / k, "first_begin_to_last_end_per_launch_ns": span / k}
+    except (OSError, ValueError, KeyError):
+        timed = None
     rec = {
         "kernel": short(fft["Name"]),
+        "timed_region_under_rocprofv3": timed,
         "n": n,
         "batch": batch,
         "kernel_launches_per_transform": launches_per_transform,
