@@ -288,23 +288,50 @@ void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, 
   }
 }
 
-// One workgroup per run of RUN work items of one filter (fft_conv_mfma4096_run_kernel); per_cu is not used.
+// The default form for fp16 storage: one workgroup per run of RUN work items of one filter, the next item's signal
+// travelling into LDS under the current item's passes (fft_conv_mfma4096_dma_kernel). RUN is the longest of 8, 4, 2
+// that still leaves six workgroups per resident slot (three slots per CU); problems too small for that, and calls
+// that ask for the resident grid (per_cu > 0), take the one-workgroup-per-item kernel.
+template <int KIND>
+void launch_conv_mfma_default(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int per_cu,
+                              hipStream_t stream) {
+  const unsigned nb = (KIND == kConvMfmaRealPair) ? ((unsigned)B + 1u) / 2u : (unsigned)B;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const unsigned long long want = 6ull * 3ull * (unsigned)cus;  // workgroups
+  auto groups = [&](unsigned run) { return (unsigned long long)((nb + run - 1) / run) * (unsigned)D; };
+  const u32x4_t* h = static_cast<const u32x4_t*>(hp);
+  if (per_cu > 0 || groups(2) < want) {
+    launch_conv_mfma<KIND>(x, hp, y, tw, B, D, per_cu, stream);
+  } else if (groups(8) >= want) {
+    fft_conv_mfma4096_dma_kernel<KIND, 8><<<dim3((unsigned)groups(8)), dim3(256), 0, stream>>>(x, h, y, tw, B, D);
+  } else if (groups(4) >= want) {
+    fft_conv_mfma4096_dma_kernel<KIND, 4><<<dim3((unsigned)groups(4)), dim3(256), 0, stream>>>(x, h, y, tw, B, D);
+  } else {
+    fft_conv_mfma4096_dma_kernel<KIND, 2><<<dim3((unsigned)groups(2)), dim3(256), 0, stream>>>(x, h, y, tw, B, D);
+  }
+}
+
+// The staged form whatever the problem size (tests: every RUN on small shapes).
 template <int KIND, int RUN>
-void launch_conv_mfma_run(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int per_cu,
+void launch_conv_mfma_dma(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int per_cu,
                           hipStream_t stream) {
   (void)per_cu;
   const unsigned nb = (KIND == kConvMfmaRealPair) ? ((unsigned)B + 1u) / 2u : (unsigned)B;
-  const unsigned runs = (nb + RUN - 1) / RUN;
-  fft_conv_mfma4096_run_kernel<KIND, RUN><<<dim3(runs * (unsigned)D), dim3(256), 0, stream>>>(
+  fft_conv_mfma4096_dma_kernel<KIND, RUN><<<dim3(((nb + RUN - 1) / RUN) * (unsigned)D), dim3(256), 0, stream>>>(
       x, static_cast<const u32x4_t*>(hp), y, tw, B, D);
 }
 
 template <int RUN>
-bool conv_mfma_run_entry(int kind, ConvEntry* out) {
+bool conv_mfma_dma_entry(int kind, ConvEntry* out) {
   switch (kind) {
-    case kConvComplex: out->launch = &launch_conv_mfma_run<kConvMfmaComplex, RUN>; return true;
-    case kConvRealIn: out->launch = &launch_conv_mfma_run<kConvMfmaRealIn, RUN>; return true;
-    case kConvRealInOut: out->launch = &launch_conv_mfma_run<kConvMfmaRealPair, RUN>; return true;
+    case kConvComplex: out->launch = &launch_conv_mfma_dma<kConvMfmaComplex, RUN>; return true;
+    case kConvRealIn: out->launch = &launch_conv_mfma_dma<kConvMfmaRealIn, RUN>; return true;
+    case kConvRealInOut: out->launch = &launch_conv_mfma_dma<kConvMfmaRealPair, RUN>; return true;
     default: return false;
   }
 }
@@ -315,7 +342,7 @@ void launch_layout_mfma(const void* h, void* hp, int D, hipStream_t stream) {
 }
 
 bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
-  if (n != 4096 || (plan != 0 && plan != 3 && !(dtype == TFFT_F16 && plan >= 5 && plan <= 7))) return false;
+  if (n != 4096 || (plan != 0 && plan != 3 && !(dtype == TFFT_F16 && plan >= 4 && plan <= 6))) return false;
   out->layout_id = kConvLayoutValu;
   if (dtype == TFFT_F16 && plan != 3) {
     // fp16 storage: both transforms on the matrix cores (fft_conv_mfma.hpp)
@@ -325,9 +352,18 @@ bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
     out->lds_bytes = 4 * (Mfma4096::OUT_IMG + Mfma4096::IMG);
     out->layout = &launch_layout_mfma;
     out->layout_id = kConvLayoutMfma;
-    if (plan == 5) return conv_mfma_run_entry<4>(kind, out);
-    if (plan == 6) return conv_mfma_run_entry<2>(kind, out);
-    if (plan == 7) return conv_mfma_run_entry<8>(kind, out);
+    // plan 0: the staged (LDS-DMA) form with RUN chosen from the problem size; 4: one workgroup per item (the
+    // resident grid of grid_blocks_per_cu belongs to it); 5, 6: the staged form with RUN = 2 / 8 whatever the size
+    if (plan == 5) return conv_mfma_dma_entry<2>(kind, out);
+    if (plan == 6) return conv_mfma_dma_entry<8>(kind, out);
+    if (plan == 0) {
+      switch (kind) {
+        case kConvComplex: out->launch = &launch_conv_mfma_default<kConvMfmaComplex>; return true;
+        case kConvRealIn: out->launch = &launch_conv_mfma_default<kConvMfmaRealIn>; return true;
+        case kConvRealInOut: out->launch = &launch_conv_mfma_default<kConvMfmaRealPair>; return true;
+        default: return false;
+      }
+    }
     switch (kind) {
       case kConvComplex: out->launch = &launch_conv_mfma<kConvMfmaComplex>; return true;
       case kConvRealIn: out->launch = &launch_conv_mfma<kConvMfmaRealIn>; return true;

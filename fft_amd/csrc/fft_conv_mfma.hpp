@@ -326,26 +326,38 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
   }
 }
 
-// The same convolution with one workgroup per RUN consecutive work items of one filter. A workgroup's life is then
-// several items long, and while one item is in its six passes the rows of the next are already on their way: the
-// one-shot kernel above has every workgroup wait for its rows, run its passes and store, with only the other
-// workgroups of the CU to fill those waits, and measures close to the SUM of its HBM time and its on-chip time.
-// To stay within 128 VGPRs (four workgroups per CU) while holding the next item's rows:
-//   * the filter spectrum of the run is loaded once and kept (items of a run share the filter);
-//   * the start / step values of the incremental pass-1 twiddles are fetched where they are used, per item and
-//     direction, from the L2-resident table (an opaque zero offset keeps the loads inside the item loop);
-//   * the inverse matrix fragments are the forward ones with the sine halves' signs flipped (8 v_xor per use).
+// 16 bytes per lane from global memory straight into LDS (no VGPR in between): lane l of the wave lands at
+// lds_byte_address + 16 l. The instruction takes its LDS base from M0, which the compiler owns: saved and restored
+// inside the statement. The load is invisible to the compiler's s_waitcnt bookkeeping; the kernel below waits for it
+// itself (s_waitcnt vmcnt(0) at a point where nothing else of its own is outstanding).
+__device__ __forceinline__ void lds_dma_16(const void* gsrc, unsigned lds_byte_address) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_address)
+      : "memory");
+}
+
+// The convolution with the NEXT work item's signal travelling into LDS while the current one is in its six
+// passes. The one-shot kernel measures close to the SUM of its HBM time and its on-chip time: a workgroup waits
+// for its rows, computes, stores, and only the other three workgroups of the CU fill those waits. Here a
+// workgroup takes RUN consecutive items of one filter; right after it has read item k's signal out of a 16 KiB
+// staging area it starts LDS-DMA loads of item k + 1's signal into that area (no registers held for it, no wait
+// until just before item k's stores), so that every workgroup keeps a load in flight under its own arithmetic.
+// LDS: two pass images + the staging area = 49 KiB, three workgroups per CU. The filter spectrum and all twiddle
+// constants stay in registers for the run.
 template <int KIND, int RUN>
-__global__ __launch_bounds__(256, 4) void fft_conv_mfma4096_run_kernel(const void* xv, const u32x4_t* __restrict__ hp,
+__global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const void* xv, const u32x4_t* __restrict__ hp,
                                                                        void* yv,  // xv and yv may alias
                                                                        const float2* __restrict__ tw, int B, int D) {
   __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + Mfma4096::IMG];
+  __shared__ __attribute__((aligned(16))) unsigned stage[4096];  // one item's signal(s) as they lie in memory
   unsigned* const img_a = lds;
   unsigned* const img_b = lds + Mfma4096::OUT_IMG;
   const int tid = threadIdx.x;
   const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
 
-  // workgroup -> (filter d, items bq0 .. bq1 - 1 of that filter)
   const int nb = (KIND == kConvMfmaRealPair) ? (B + 1) >> 1 : B;
   const int runs = (nb + RUN - 1) / RUN;
   const int d = blockIdx.x / runs;
@@ -353,34 +365,51 @@ __global__ __launch_bounds__(256, 4) void fft_conv_mfma4096_run_kernel(const voi
   const int bq0 = (blockIdx.x - d * runs) * RUN;
   const int bq1 = min(nb, bq0 + RUN);
 
-  u32x4_t rows[4];
-  auto request_rows = [&](int bq) {
-    const int b0 = (KIND == kConvMfmaRealPair) ? 2 * bq : bq;
-    const long long s0 = (long long)b0 * D + d;
+  // first signal index of item bq, and whether a second signal rides along (real pairs)
+  auto first_signal = [&](int bq) { return (long long)((KIND == kConvMfmaRealPair) ? 2 * bq : bq) * D + d; };
+  auto has_second = [&](int bq) { return (KIND == kConvMfmaRealPair) && (2 * bq + 1 < B); };
+
+  // wave w copies 1 KiB pieces: piece (round, w) of the staging area = bytes [4096 round + 1024 w, + 1024)
+  const unsigned stage_lds = (unsigned)(uintptr_t)stage;
+  const unsigned wave_piece = __builtin_amdgcn_readfirstlane(stage_lds + 1024u * (unsigned)w);
+  auto start_dma = [&](int bq) {
+    const long long s0 = first_signal(bq);
     if constexpr (KIND == kConvMfmaComplex) {
-      const u32x4_t* src = static_cast<const u32x4_t*>(xv) + s0 * 1024 + 16 * w + i;
+      const u32x4_t* src = static_cast<const u32x4_t*>(xv) + s0 * 1024 + tid;  // 16 KiB, linear
 #pragma unroll
-      for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + (4 * G + g) * 64);
+      for (int r = 0; r < 4; ++r) lds_dma_16(src + 256 * r, wave_piece + 4096u * r);
     } else {
-      const bool two = (KIND == kConvMfmaRealPair) && (b0 + 1 < B);
-      const u32x2_t* src0 = static_cast<const u32x2_t*>(xv) + s0 * 1024 + 16 * w + i;
-      const u32x2_t* src1 = src0 + (long long)D * 1024;
+      const u32x4_t* src0 = static_cast<const u32x4_t*>(xv) + s0 * 512 + tid;  // 8 KiB per real signal
 #pragma unroll
-      for (int G = 0; G < 4; ++G) {
-        const u32x2_t a = __builtin_nontemporal_load(src0 + (4 * G + g) * 64);
-        u32x2_t c = {0u, 0u};
-        if (two) c = __builtin_nontemporal_load(src1 + (4 * G + g) * 64);
-        rows[G] = u32x4_t{(a.x & 0xffffu) | (c.x << 16), (a.x >> 16) | (c.x & 0xffff0000u),
-                          (a.y & 0xffffu) | (c.y << 16), (a.y >> 16) | (c.y & 0xffff0000u)};
+      for (int r = 0; r < 2; ++r) lds_dma_16(src0 + 256 * r, wave_piece + 4096u * r);
+      if (has_second(bq)) {  // uniform over the workgroup
+        const u32x4_t* src1 = src0 + (long long)D * 512;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) lds_dma_16(src1 + 256 * r, wave_piece + 8192u + 4096u * r);
       }
     }
   };
-  request_rows(bq0);
+  start_dma(bq0);
 
-  // ---- kept for the whole run: the filter in lane order, the forward matrix fragments, the pass-2 twiddles
+  // ---- constants of the run, all in registers
   u32x4_t hreg[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) hreg[t] = hp[(long long)d * 1024 + t * 256 + tid];
+  const float4* ctab = reinterpret_cast<const float4*>(tw + ConvMfma4096::OFFSET);
+  c32 start_g[4], start_c[4], step_g[4], step_c[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 a = ctab[h * 256 + tid], b = ctab[512 + h * 256 + tid];
+    const float4 p = ctab[1024 + h * 4 + g], q = ctab[1032 + h * 4 + g];
+    start_g[2 * h] = make_float2(a.x, a.y);
+    start_g[2 * h + 1] = make_float2(a.z, a.w);
+    start_c[2 * h] = make_float2(b.x, b.y);
+    start_c[2 * h + 1] = make_float2(b.z, b.w);
+    step_g[2 * h] = make_float2(p.x, p.y);
+    step_g[2 * h + 1] = make_float2(p.z, p.w);
+    step_c[2 * h] = make_float2(q.x, q.y);
+    step_c[2 * h + 1] = make_float2(q.z, q.w);
+  }
   h2_t t2[4];
   {
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
@@ -391,32 +420,40 @@ __global__ __launch_bounds__(256, 4) void fft_conv_mfma4096_run_kernel(const voi
     t2[3] = pack_h2(__uint_as_float(q.z), __uint_as_float(q.w));
   }
   MfmaDir<true> fwd;
+  MfmaDir<false> inv;
   fwd.init(tw, tid);
-  const float4* const ctab = reinterpret_cast<const float4*>(tw + ConvMfma4096::OFFSET);
-  // start / step of one column map (0: columns 64w + 4i + j, the rows from memory; 1: 16 (4w + t) + i, the chained
-  // registers), fetched through an offset the optimiser cannot see is zero
-  auto fetch_twiddles = [&](int map, c32 (&start)[4], c32 (&step)[4]) {
-    int opaque = 0;
-    asm volatile("" : "+v"(opaque));
-    const float4* tab = ctab + opaque;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float4 a = tab[map * 512 + h * 256 + tid];
-      const float4 p = tab[1024 + map * 8 + h * 4 + g];
-      start[2 * h] = make_float2(a.x, a.y);
-      start[2 * h + 1] = make_float2(a.z, a.w);
-      step[2 * h] = make_float2(p.x, p.y);
-      step[2 * h + 1] = make_float2(p.z, p.w);
-    }
-  };
+  inv.init(tw, tid);
 
+  // the first item's signal: every wave waits for its own pieces (and for the table loads above), then all meet
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
   for (int bq = bq0; bq < bq1; ++bq) {
-    const int b0 = (KIND == kConvMfmaRealPair) ? 2 * bq : bq;
-    const bool two = (KIND == kConvMfmaRealPair) && (b0 + 1 < B);
-    const long long s0 = (long long)b0 * D + d, s1 = s0 + D;
+    const long long s0 = first_signal(bq), s1 = s0 + D;
+    const bool two = has_second(bq);
+    // the twiddle chains W^(k1 c0) (W^(k1 q))^s are rebuilt per item from their start values: hoisted out of this
+    // loop, their 24 powers per column map would be live for the whole run
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      start_g[r] = fresh<false>(start_g[r]);
+      start_c[r] = fresh<false>(start_c[r]);
+    }
+    __syncthreads();  // the staging area is complete (each wave waited for its pieces before arriving here)
 
-    // ---- forward transform
+    // ---- this lane's rows 4G + g, columns 64w + 4i .. 4i + 3, out of the staging area
+    u32x4_t rows[4];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+      if constexpr (KIND == kConvMfmaComplex) {
+        rows[G] = *reinterpret_cast<const u32x4_t*>(&stage[4 * ((4 * G + g) * 64 + 16 * w + i)]);
+      } else {
+        const int at = 2 * ((4 * G + g) * 64 + 16 * w + i);  // dword index of four real points
+        const u32x2_t a = *reinterpret_cast<const u32x2_t*>(&stage[at]);
+        u32x2_t c = {0u, 0u};
+        if (two) c = *reinterpret_cast<const u32x2_t*>(&stage[2048 + at]);
+        rows[G] = u32x4_t{(a.x & 0xffffu) | (c.x << 16), (a.x >> 16) | (c.x & 0xffff0000u),
+                          (a.y & 0xffffu) | (c.y << 16), (a.y >> 16) | (c.y & 0xffff0000u)};
+      }
+    }
     u32x4_t packed[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -431,39 +468,23 @@ __global__ __launch_bounds__(256, 4) void fft_conv_mfma4096_run_kernel(const voi
       a2 = s[0]; a3 = s[1];
       packed[j] = u32x4_t{a0, a1, a2, a3};
     }
-    if (bq + 1 < bq1) request_rows(bq + 1);  // lands under this item's passes
-    {
-      c32 start[4], step[4];
-      fetch_twiddles(0, start, step);
-      mfma_pass1<true, false>(fwd, packed, start, step, img_a, w, g, i);
-    }
+    __syncthreads();  // every wave has its rows in registers: the staging area is free
+    if (bq + 1 < bq1) start_dma(bq + 1);
+
+    // ---- forward transform, product, inverse transform
+    mfma_pass1<true, false>(fwd, packed, start_g, step_g, img_a, w, g, i);
     __syncthreads();
     mfma_pass2<true>(fwd, t2, img_a, img_b, w, g, i);
     __syncthreads();
     mfma_f4 xr[4], xi[4];
     mfma_pass3<true>(fwd, img_b, xr, xi, w, g, i);
-
-    // ---- product with the filter spectrum, rounded to fp16: the inverse's first-pass fragments
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         packed[t][r] = cmul_h2<false>(pack_h2(xr[t][r], xi[t][r]), __builtin_bit_cast(h2_t, (unsigned)hreg[t][r]));
     }
-
-    // ---- inverse transform: the conjugate matrix = the forward rows with the signs of their sine halves flipped
-    // ((cos, sin) pairs in the real-output rows, (-sin, cos) in the imaginary-output rows)
-    MfmaDir<false> inv;
-    {
-      const u32x4_t fr = __builtin_bit_cast(u32x4_t, fwd.a_re), fi = __builtin_bit_cast(u32x4_t, fwd.a_im);
-      inv.a_re = __builtin_bit_cast(mfma_h8, fr ^ 0x80000000u);
-      inv.a_im = __builtin_bit_cast(mfma_h8, fi ^ 0x00008000u);
-    }
-    {
-      c32 start[4], step[4];
-      fetch_twiddles(1, start, step);
-      mfma_pass1<false, true>(inv, packed, start, step, img_a, w, g, i);
-    }
+    mfma_pass1<false, true>(inv, packed, start_c, step_c, img_a, w, g, i);
     __syncthreads();
     mfma_pass2<false>(inv, t2, img_a, img_b, w, g, i);
     __syncthreads();
@@ -478,20 +499,23 @@ __global__ __launch_bounds__(256, 4) void fft_conv_mfma4096_run_kernel(const voi
     }
     __syncthreads();
 
-    // ---- natural order out
+    // ---- natural order out. The next signal has had the six passes to arrive: waiting for it here, before this
+    // item's stores are issued, leaves nothing else outstanding to wait for.
+    u32x4_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[4 * (tid + 256 * q) + 4 * (w + 4 * q)]);
       if constexpr (KIND == kConvMfmaRealPair) {
-        const u32x2_t y0 = {(v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16)};
-        const u32x2_t y1 = {(v.x >> 16) | (v.y & 0xffff0000u), (v.z >> 16) | (v.w & 0xffff0000u)};
+        const u32x2_t y0 = {(v[q].x & 0xffffu) | (v[q].y << 16), (v[q].z & 0xffffu) | (v[q].w << 16)};
+        const u32x2_t y1 = {(v[q].x >> 16) | (v[q].y & 0xffff0000u), (v[q].z >> 16) | (v[q].w & 0xffff0000u)};
         __builtin_nontemporal_store(y0, static_cast<u32x2_t*>(yv) + s0 * 1024 + tid + 256 * q);
         if (two) __builtin_nontemporal_store(y1, static_cast<u32x2_t*>(yv) + s1 * 1024 + tid + 256 * q);
       } else {
-        __builtin_nontemporal_store(v, static_cast<u32x4_t*>(yv) + s0 * 1024 + tid + 256 * q);
+        __builtin_nontemporal_store(v[q], static_cast<u32x4_t*>(yv) + s0 * 1024 + tid + 256 * q);
       }
     }
-    __syncthreads();  // the output image is read before the next item's first pass overwrites it
   }
 }
 

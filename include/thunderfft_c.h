@@ -95,14 +95,16 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *                        10 = one workgroup per tile with incrementally built twiddles, 11 = resident grid,
  *                        12 = plan 10 with one LDS image (n <= 4096); 5, 7 = one LDS image (n = 4096); 8 = split
  *                        bf16 matrix (bf16, n = 4096). A plan a length does not have returns
- *                        TFFT_ERR_UNSUPPORTED. For the convolution entry points plan 3 selects the fp32-VALU
- *                        kernels for fp16 storage.
+ *                        TFFT_ERR_UNSUPPORTED. For the convolution entry points (fp16 storage): 0 = one workgroup
+ *                        per run of 2 ... 8 signals of one filter, the next signal travelling into LDS under the
+ *                        current one's passes (small problems fall back to plan 4); 3 = the fp32-VALU kernels;
+ *                        4 = one workgroup per signal; 5, 6 = the plan-0 kernel with runs of 2 / 8 whatever the size.
  *   xcd_run_log2       : -1 = the kernel's default; L >= 0 = every XCD takes runs of 2^L consecutive chunks of
  *                        the batch (0 = chunk order equals launch order); results do not depend on it
  *   grid_blocks_per_cu : resident grid of value * CU count workgroups that walk the batch (0 = default: one
  *                        workgroup per chunk of transforms, or the resident size of a kernel that is resident
- *                        by default). For the fp16 convolution: workgroups per CU of its resident grid
- *                        (0 = one workgroup per signal, which measured faster).
+ *                        by default). For the fp16 convolution: workgroups per CU of the resident grid of its
+ *                        one-workgroup-per-signal kernel (plans 0 and 4; 0 = no resident grid).
  *   grid_blocks        : resident grid of exactly value workgroups (overrides the per-CU form)
  *   extra_lds          : bytes of unused dynamic LDS per workgroup, to lower occupancy
  *   workspace(+_bytes) : multi-pass lengths (fp32, n > 16384): caller-owned scratch of at least n points
@@ -244,8 +246,8 @@ int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_
  * alias d_h_freq. */
 int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream);
 
-/* The two convolution calls with per-call options (opt == NULL: exactly the calls above). The kernels behind
- * plan 0 and plan 3 read the permuted filters in different orders: the library remembers which order each
+/* The two convolution calls with per-call options (opt == NULL: exactly the calls above). The matrix-core kernels
+ * (plans 0, 4, 5, 6) and the fp32-VALU kernels (plan 3) read the permuted filters in different orders: the library remembers which order each
  * d_h_perm buffer was last written in and tfft_conv_exec(_opt) returns TFFT_ERR_INVALID when asked to read a
  * buffer with the other kernel. */
 int tfft_conv_exec_opt(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,
