@@ -121,8 +121,11 @@ def recorded_traffic(kernel_tag, signature):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed launches (default 20; 100 for 16-bit storage)")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed launches before them (default 3; 50 for 16-bit storage, whose matrix-core kernels "
+                         "take tens of milliseconds of sustained work to reach their rate)")
     ap.add_argument("--n", "--fft-len", dest="n", type=int, default=N_FFT,
                     help="transform length (use --fft-len behind torch.distributed.run, whose own parser takes "
                          "--n for an abbreviation)")
@@ -143,6 +146,13 @@ def parse_args(argv=None):
         ap.error("--gpus must be >= 1")
     if args.batch <= 0:
         args.batch = max(1, POINTS // args.n)
+    # 3 + 20 launches of a 16-bit configuration read 67-70 % of 8 TB/s where 50 + 100 read 78-80 %: the device is
+    # still settling. fp32 kernels show no such ramp (77.6 % at 3 + 20, 76.4 % at 50 + 100).
+    settled = args.dtype != "fp32"
+    if args.steps is None:
+        args.steps = 100 if settled else 20
+    if args.warmup is None:
+        args.warmup = 50 if settled else 3
     # x -> y for every storage type (the call shape of the reference's fft1d sample, sample/fft1d/main.cu:116);
     # --in-place is the reference bench's form (sample/bench/baseline/thunderfft_bench.h:124-125). Once the device
     # has settled the two forms run at the same rate for all three storage types.
