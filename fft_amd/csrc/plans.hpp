@@ -203,13 +203,14 @@ bool launch_repeat_bf16(int n, const void* in, void* out, const float2* tw, long
                         hipStream_t s);
 
 // The matrix-core kernels of one 16-bit storage type for N = 256 R1 < 4096. Mode 0, the default: N = 256 (no first
-// pass, no twiddle table to fetch) one workgroup per tile with one LDS image; otherwise a resident grid with the
-// pass-1 twiddles from the lane-ordered table. 6: one workgroup per tile, table; 10: one workgroup per tile, twiddles
-// built incrementally; 12: the same with one LDS image (eight workgroups per CU); 11: resident grid.
+// pass, no twiddle table to fetch) one workgroup per tile with one LDS image (12); otherwise one workgroup per tile
+// with two images and the pass-1 twiddles built incrementally (10): on a settled device 77-80 % of 8 TB/s against
+// 76 % for the resident grid with the lane-ordered twiddle table (11), which had looked level while the device was
+// still ramping up. 6: one workgroup per tile, table; 12: plan 10 with one LDS image (eight workgroups per CU).
 template <class T16, int R1>
 bool mfma_entry_for(bool forward, int mode, KernelEntry* out) {
   constexpr bool INCR = R1 > 1;
-  if (mode == 0) mode = R1 == 1 ? 12 : 11;
+  if (mode == 0) mode = R1 == 1 ? 12 : 10;
   if (mode == 11) { *out = forward ? make_mfma_entry<T16, true, true, 3, true, R1>() : make_mfma_entry<T16, false, true, 3, true, R1>(); return true; }
   if (mode == 6) { *out = forward ? make_mfma_entry<T16, true, true, 4, false, R1>() : make_mfma_entry<T16, false, true, 4, false, R1>(); return true; }
   if (mode == 10) { *out = forward ? make_mfma_entry<T16, true, true, 4, false, R1, INCR>() : make_mfma_entry<T16, false, true, 4, false, R1, INCR>(); return true; }
