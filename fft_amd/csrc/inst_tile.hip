@@ -30,7 +30,9 @@ bool entry(bool forward, int iomode, TileEntry* out) {
 
 }  // namespace
 
-bool lookup_tile(int n, bool forward, int iomode, TileEntry* out) {
+bool lookup_tile(int n, bool forward, int iomode, bool wide, TileEntry* out) {
+  if (wide && n == 256) return entry<Tile256Wide>(forward, iomode, out);
+  if (wide && n == 512) return entry<Tile512Wide>(forward, iomode, out);
   switch (n) {
     case 64: return entry<Tile64>(forward, iomode, out);
     case 128: return entry<Tile128>(forward, iomode, out);

@@ -412,7 +412,7 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info) {
     if (!factor_big(ilog2(n), &nf, f))
       return fail(TFFT_ERR_UNSUPPORTED, "tfft_get_plan_info: no multi-pass plan for n=%d", n);
     tfft::TileEntry t;
-    tfft::lookup_tile(f[nf - 1], true, tfft::kTileOutCol, &t);
+    tfft::lookup_tile(f[nf - 1], true, tfft::kTileOutCol, false, &t);
     info->n = n;
     info->threads_per_block = t.threads;
     info->transforms_per_block = t.tpb;  // short transforms per tile of the last sweep
@@ -483,9 +483,13 @@ int tfft_workspace_bytes(int dtype, int n, long long batch, unsigned long long* 
   return TFFT_OK;
 }
 
+// Plans of a multi-pass length: 0 = 64 KiB tiles; 3, 4, 5 = 128 KiB tiles for the 256- and 512-point sweeps, the
+// 512-point sweeps only, the 256-point sweeps only (A/B partners).
+static int wide_mask_of(int plan) { return plan == 3 ? 3 : plan == 4 ? 2 : plan == 5 ? 1 : 0; }
+
 // The sweeps of `batch` large transforms through `scratch`, which holds `scratch_batch` transforms of n points.
 static int enqueue_big(const BigPlan& p, int n, bool fwd, const void* d_in, void* d_out, long long batch,
-                       float4* scratch, long long scratch_batch, int xcd_opt, hipStream_t s) {
+                       float4* scratch, long long scratch_batch, int xcd_opt, int wide_mask, hipStream_t s) {
   constexpr int kSweep = tfft::kTileInCol | tfft::kTileOutCol | tfft::kTileTwiddle;
   for (long long b = 0; b < batch; b += scratch_batch) {
     const long long group = std::min<long long>(scratch_batch, batch - b);  // transforms per launch
@@ -496,7 +500,8 @@ static int enqueue_big(const BigPlan& p, int n, bool fwd, const void* d_in, void
     for (int i = 0; i < p.nf; ++i) {
       const bool last = (i == p.nf - 1);
       tfft::TileEntry t;
-      if (!tfft::lookup_tile(p.f[i], fwd, last ? tfft::kTileOutCol : kSweep, &t))
+      const bool wide = (p.f[i] == 256 && (wide_mask & 1)) || (p.f[i] == 512 && (wide_mask & 2));
+      if (!tfft::lookup_tile(p.f[i], fwd, last ? tfft::kTileOutCol : kSweep, wide, &t))
         return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c: no tile kernel of length %d", p.f[i]);
       tfft::TileArgs a{};
       a.xcd_log2 = xcd_opt >= 0 ? xcd_opt : 4;  // measured: +1 ... 1.5 points on the sweeps
@@ -560,7 +565,7 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
     if (it == g_big.end())
       return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c: call tfft_initialize(fp32, %d) on device %d first", n, dev);
     return enqueue_big(it->second, n, forward != 0, d_in, d_out, batch, static_cast<float4*>(opt.workspace),
-                       (long long)(opt.workspace_bytes / per), opt.xcd_run_log2, s);
+                       (long long)(opt.workspace_bytes / per), opt.xcd_run_log2, wide_mask_of(opt.plan), s);
   }
   // library-owned scratch: enqueue under the lock, behind the previous user of the scratch
   WriteLock lock(g_mu);
@@ -580,7 +585,7 @@ static int exec_big(int n, int forward, const void* d_in, void* d_out, long long
   // always behind the previous user, also on "the same" stream: a handle can be that of a destroyed and re-created
   // stream, and a wait on the stream the event was recorded on costs nothing
   if (eager && p.used) TFFT_HIP(hipStreamWaitEvent(s, p.done, 0));
-  const int rc = enqueue_big(p, n, forward != 0, d_in, d_out, batch, p.work, p.work_batch, opt.xcd_run_log2, s);
+  const int rc = enqueue_big(p, n, forward != 0, d_in, d_out, batch, p.work, p.work_batch, opt.xcd_run_log2, wide_mask_of(opt.plan), s);
   if (eager) {
     // recorded even after a failed sweep: whatever was enqueued still uses the scratch
     TFFT_HIP(hipEventRecord(p.done, s));
@@ -663,7 +668,8 @@ int tfft_exec_c2c_opt(int dtype, int n, int forward, const void* d_in, void* d_o
   if (batch == 0) return TFFT_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == TFFT_F32 && n > kMaxLdsN) {
-    if (opt.plan != 0) return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c_opt: multi-pass lengths have one plan");
+    if (opt.plan != 0 && !(opt.plan >= 3 && opt.plan <= 5))
+      return fail(TFFT_ERR_UNSUPPORTED, "tfft_exec_c2c_opt: multi-pass lengths have plans 0, 3, 4 and 5");
     if (int rc = exec_big(n, forward, d_in, d_out, batch, s, opt)) return rc;
     return finish_launch(s);
   }
@@ -691,7 +697,14 @@ int tfft_exec_c2c_static(int dtype, int n, int forward, const void* d_in, void* 
   TFFT_HIP(hipGetDevice(&dev));
   float4* scratch = nullptr;
   {
-    WriteLock lock(g_mu);  // the address table is filled on first use per device (tfft_initialize does that)
+    // tfft_initialize has filled the address table for this device; only a call on a device that never saw an
+    // initialize of its own takes the exclusive lock
+    ReadLock lock(g_mu);
+    auto known = g_static_scratch_addr.find(dev);
+    if (known != g_static_scratch_addr.end()) scratch = known->second;
+  }
+  if (!scratch) {
+    WriteLock lock(g_mu);
     if (int rc = static_scratch_for(dev, &scratch)) return rc;
   }
   ReadLock lock(g_mu);
@@ -699,7 +712,7 @@ int tfft_exec_c2c_static(int dtype, int n, int forward, const void* d_in, void* 
   if (it == g_big.end())
     return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_exec_c2c_static: call tfft_initialize(fp32, %d) on device %d first", n, dev);
   // Every sweep writes the part of the scratch it later reads, so nothing needs clearing between calls.
-  if (int rc = enqueue_big(it->second, n, forward != 0, d_in, d_out, batch, scratch, kStaticScratchPoints / n, -1, s)) return rc;
+  if (int rc = enqueue_big(it->second, n, forward != 0, d_in, d_out, batch, scratch, kStaticScratchPoints / n, -1, 0, s)) return rc;
   return finish_launch(s);
 }
 

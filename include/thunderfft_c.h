@@ -95,7 +95,9 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *                        10 = one workgroup per tile with incrementally built twiddles, 11 = resident grid,
  *                        12 = plan 10 with one LDS image (n <= 4096); 5, 7 = one LDS image (n = 4096); 8 = split
  *                        bf16 matrix (bf16, n = 4096). A plan a length does not have returns
- *                        TFFT_ERR_UNSUPPORTED. For the convolution entry points (fp16 storage): 0 = one workgroup
+ *                        TFFT_ERR_UNSUPPORTED. Multi-pass lengths (fp32, n > 16384): 3, 4, 5 = 128 KiB tiles
+ *                        (twice the transforms per tile) for the 256- and 512-point sweeps, the 512-point sweeps
+ *                        only, the 256-point sweeps only; same results bit for bit. For the convolution entry points (fp16 storage): 0 = one workgroup
  *                        per run of 2 ... 8 signals of one filter, the next signal travelling into LDS under the
  *                        current one's passes (small problems fall back to plan 4); 3 = the fp32-VALU kernels;
  *                        4 = one workgroup per signal; 5, 6 = the plan-0 kernel with runs of 2 / 8 whatever the size.

@@ -64,6 +64,29 @@ def test_very_big_vs_fp64_fft_and_roundtrip(oracle_mod, lg):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("lg", (16, 17, 18, 22))
+@pytest.mark.parametrize("forward", (True, False))
+def test_wide_tile_plans_equal_the_default(lg, forward):
+    """Plans 3, 4, 5 of a multi-pass length run their 256- and 512-point sweeps on tiles of twice as many transforms;
+    every transform goes through the same arithmetic, so the results are the default's bit for bit. Plans the
+    multi-pass lengths do not have are refused."""
+    n = 1 << lg
+    batch = 3 if lg <= 18 else 1
+    g = torch.Generator(device="cuda").manual_seed(100 + lg)
+    x = torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1
+    fft_amd.ThunderFFTInitialize("fp32", n)
+    want = torch.empty_like(x)
+    fft_amd.ThunderFFT_global(x, want, batch, n, forward)
+    for plan in (3, 4, 5):
+        got = torch.full_like(x, float("nan"))
+        fft_amd.ThunderFFT_global(x, got, batch, n, forward, options={"plan": plan})
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"n=2^{lg} plan {plan}"
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        fft_amd.ThunderFFT_global(x, want, batch, n, forward, options={"plan": 6})
+    assert e.value.code == 1  # TFFT_ERR_UNSUPPORTED
+
+
 def test_batch_larger_than_the_scratch_round(oracle_mod):
     """The library folds batches through a scratch of 2^26 points: 2049 transforms of 2^15 points take two
     rounds. Every transform equals the one a small call computes; scattered ones are checked against the oracle."""
@@ -134,7 +157,7 @@ def test_caller_workspace(oracle_mod):
     with pytest.raises(fft_amd.ThunderFFTError) as e:
         fft_amd.ThunderFFT_global(x, got, batch, n, True,
                                   options={"workspace": torch.empty(lo - 16, dtype=torch.uint8, device="cuda")})
-    assert e.value.code == 3
+    assert e.value.code == 1  # TFFT_ERR_UNSUPPORTED
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     w1 = torch.empty(best, dtype=torch.uint8, device="cuda")
     w2 = torch.empty(best, dtype=torch.uint8, device="cuda")

@@ -246,6 +246,8 @@ TILE_CONFIGS = [
     (256, 16, 16, 16, 32),
     (512, 32, 16, 32, 16),
     (1024, 32, 32, 32, 16),
+    (512, 32, 16, 32, 32),
+    (256, 32, 16, 16, 64),
 ]
 
 
