@@ -157,7 +157,7 @@ def test_caller_workspace(oracle_mod):
     with pytest.raises(fft_amd.ThunderFFTError) as e:
         fft_amd.ThunderFFT_global(x, got, batch, n, True,
                                   options={"workspace": torch.empty(lo - 16, dtype=torch.uint8, device="cuda")})
-    assert e.value.code == 1  # TFFT_ERR_UNSUPPORTED
+    assert e.value.code == 3
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     w1 = torch.empty(best, dtype=torch.uint8, device="cuda")
     w2 = torch.empty(best, dtype=torch.uint8, device="cuda")
