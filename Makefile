@@ -24,7 +24,7 @@ CONVBENCH  := bench/thff_conv1d_fullfft4096 bench/thff_conv1d bench/thff_fft
 
 .PHONY: all lib oracle bench examples clean
 all: lib oracle bench examples
-examples: examples/libspectral_mask.so examples/libreference_shape.so
+examples: examples/libspectral_mask.so examples/libreference_shape.so examples/consumer
 lib: $(LIB)
 oracle: $(ORACLE)
 bench: $(BENCH) $(CONVBENCH)
@@ -69,5 +69,11 @@ examples/libspectral_mask.so: examples/spectral_mask.hip include/thunderfft/thun
 examples/libreference_shape.so: examples/reference_shape.hip include/thunderfft/thunderfft.cuh include/thunderfft/thunderfft_device.hpp include/thunderfft/thunderfft_layout_tuned.h $(KERNEL_HDRS) $(LIB)
 	$(HIPCC) $(HIPFLAGS) -Iinclude -shared -o $@ $< -L$(LIBDIR) -lthunderfft_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
+# the program of examples/cmake_consumer (an outside project on the `thunderfft` CMake target), built here so that the
+# GPU tests can run it without configuring CMake on the box
+examples/consumer: examples/cmake_consumer/main.cpp include/thunderfft/thunderfft.cuh include/thunderfft_c.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude -o $@ $< \
+	    -L$(LIBDIR) -lthunderfft_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
 clean:
-	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH) $(CONVBENCH) examples/libspectral_mask.so examples/libreference_shape.so
+	rm -rf $(BUILD) $(LIB) $(ORACLE) $(BENCH) $(CONVBENCH) examples/libspectral_mask.so examples/libreference_shape.so examples/consumer

@@ -109,3 +109,14 @@ def test_bench_py_prints_one_json_line_with_the_contract_keys(extra):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_cmake_consumer_program():
+    """examples/cmake_consumer/main.cpp, the program an outside CMake project builds on the `thunderfft` target
+    (tests/test_cmake_build.py builds it that way on the CPU): Initialize, ThunderFFT_global, Finalize on tones."""
+    exe = os.path.join(ROOT, "examples", "consumer")
+    assert os.path.exists(exe), "build it with `make examples`"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"consumer: N=1024 batch=64 max_abs_err=([0-9.eE+-]+)", r.stdout)
+    assert m and float(m.group(1)) < 1e-2, r.stdout
