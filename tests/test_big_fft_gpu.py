@@ -331,7 +331,7 @@ def test_distributed_2p30_on_eight_virtual_ranks():
 
 def test_dist_pass_kernels_match_their_definition():
     """tfft_dist_permute and tfft_dist_radix against the fp64 evaluation of their definitions (NumpyOps) on
-    shapes that are not multiples of the 64 x 64 tile, with batch strides, with and without the twiddle, both
+    shapes that are not multiples of the kernels' tiles (64 x 64 transposing, 8 x 512 copying), with batch strides, with and without the twiddle, both
     directions, in place for the radix pass."""
     from dist_reference import NumpyOps
     from fft_amd.distributed import HipOps, permute_spec, radix_spec
@@ -349,6 +349,15 @@ def test_dist_pass_kernels_match_their_definition():
         permute_spec(nb1=4, nb2=1, ni=33, nj=200, in_b1=33 * 200, in_i=200, out_b1=200, out_j=4 * 200, transpose=0),
         permute_spec(nb1=2, nb2=1, ni=10, nj=64, in_b1=640, in_i=64, out_b1=640, out_j=64, transpose=0,
                      twiddle=dict(n=n_tw, p0=1, pi=1, q0=0, qb1=64, qb2=0, qj=1)),
+        # copies wider than one 512-point row segment, ragged in both directions, with a twiddle that depends on
+        # every index
+        permute_spec(nb1=2, nb2=2, ni=11, nj=1030, in_b1=2 * 11 * 1032, in_b2=11 * 1032, in_i=1032, out_b1=1030,
+                     out_b2=2 * 1030 * 12, out_j=2 * 1030, transpose=0,
+                     twiddle=dict(n=n_tw, p0=3, pi=7, q0=11, qb1=13, qb2=1000, qj=9)),
+        # long rows, no twiddle: the kernel that moves runs of 4096 points of one row (ragged last run)
+        permute_spec(nb1=2, nb2=1, ni=3, nj=4100, in_b1=3 * 4100, in_i=4100, out_b1=4102, out_j=2 * 4102, transpose=0),
+        # transposing with the larger pitch on the output side (tiles then walk along i first)
+        permute_spec(nb1=1, nb2=2, ni=130, nj=66, in_b1=0, in_b2=130 * 66, in_i=66, out_b2=132, out_j=2 * 132 + 4),
     ]
     for spec in specs:
         points = 1 << 16
