@@ -122,9 +122,9 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed launches (default 20; 100 for 16-bit storage)")
+                    help="timed launches (default 20; 100 for 16-bit storage and for fp32 N = 16384)")
     ap.add_argument("--warmup", type=int, default=None,
-                    help="untimed launches before them (default 3; 50 for 16-bit storage, whose matrix-core kernels "
+                    help="untimed launches before them (default 3; 50 for 16-bit storage and fp32 N = 16384, whose kernels "
                          "take tens of milliseconds of sustained work to reach their rate)")
     ap.add_argument("--n", "--fft-len", dest="n", type=int, default=N_FFT,
                     help="transform length (use --fft-len behind torch.distributed.run, whose own parser takes "
@@ -147,8 +147,10 @@ def parse_args(argv=None):
     if args.batch <= 0:
         args.batch = max(1, POINTS // args.n)
     # 3 + 20 launches of a 16-bit configuration read 67-70 % of 8 TB/s where 50 + 100 read 78-80 %: the device is
-    # still settling. fp32 kernels show no such ramp (77.6 % at 3 + 20, 76.4 % at 50 + 100).
-    settled = args.dtype != "fp32"
+    # still settling. The fp32 kernels up to N = 8192 show no such ramp (77.6 % at 3 + 20, 76.4 % at 50 + 100); the
+    # N = 16384 kernel (two workgroups per CU, the one length that is latency- rather than bandwidth-limited) does:
+    # 72 % over the first 3 + 20 launches of a process, 75.2-75.5 % at 50 + 100, three processes in a row each way.
+    settled = args.dtype != "fp32" or args.n == 16384
     if args.steps is None:
         args.steps = 100 if settled else 20
     if args.warmup is None:
@@ -187,6 +189,8 @@ def kernel_label(dtype, n, radix):
                     "strided column sweeps with four-step twiddles, last sweep writes natural order")
         if n == 8192:
             return "tfft::fft_dit_kernel<Plan4096, forward> (two interleaved 4096-point transforms per workgroup)"
+        if n == 16384:
+            return f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward, straight-line>"
         return f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>"
     if 256 <= n <= 4096:
         return f"tfft::fft_mfma4096_kernel<{dtype}, forward, N={n}>"

@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
   auto run = [&](const Variant& v, float* dst) {
     if (dst == out) dst = out + (size_t)v.out_offset_kib * 256;
     if (v.kind == 0) {
-      fft_lds_kernel<P, IO, true, kModeFFT><<<dim3((unsigned)batch), dim3(P::WG)>>>(
+      fft_lds_kernel<P, IO, true, kModeFFT, false><<<dim3((unsigned)batch), dim3(P::WG)>>>(
           reinterpret_cast<const IO::raw*>(in), reinterpret_cast<IO::raw*>(dst), d_tw, batch, batch, v.xcd_log2);
     } else {
       auto k = v.kind == 1 ? resident_stagger<true, false> : resident_stagger<true, true>;

@@ -3,7 +3,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libthunderfft_hip.so")
+# THUNDERFFT_HIP_LIB: another build of the same library (A/B timing of two builds, an installed copy); it must export
+# the same C ABI. There is still no fallback: the named file is the one that is loaded, or the import fails.
+LIB_PATH = os.environ.get("THUNDERFFT_HIP_LIB") or os.path.join(_HERE, "lib", "libthunderfft_hip.so")
 
 # Every symbol include/thunderfft_c.h declares; tests check the list against the header.
 SYMBOLS = (

@@ -4,7 +4,12 @@
 // with global memory -> registers -> BlockFFT::transform -> global memory.
 //
 //   launch  : one workgroup per chunk by default (the dispatcher hands chunks out in address order as workgroups
-//             retire); a smaller grid walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... (resident form)
+//             retire); a smaller grid walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... (resident form).
+//             The two are separate instantiations (LOOP): as the single trip of the loop, a one-shot workgroup's rows
+//             shared registers with the loop-carried ones, and the register allocator made room by waiting for the
+//             first rows to arrive and moving them before it requested the last ones (N = 16384: two of a
+//             thread's sixteen loads left one memory round trip late). The straight-line form has every load in
+//             flight before the first wait.
 //   loads   : the first chunk's rows are requested before anything else is set up: a workgroup's life starts
 //             with that HBM round trip (worth 6-8 %)
 //   PREFETCH plans request the rows of the next chunk as soon as the current rows are unpacked, so they land
@@ -17,7 +22,7 @@
 
 namespace tfft {
 
-template <class P, class IO, bool FWD, int MODE>
+template <class P, class IO, bool FWD, int MODE, bool LOOP>
 __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename IO::raw* in, typename IO::raw* out,
                                                                  const float2* __restrict__ tw, long long batch,
                                                                  long long nchunks, int xcd_log2) {
@@ -34,6 +39,16 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
     return (int)(left < TPB ? left : TPB);
   };
   raw pre[NRAW];
+  if constexpr (!LOOP) {
+    // one workgroup per chunk (the launcher picks this instantiation when the grid covers every chunk)
+    const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
+    f.template load<IO>(in + chunk * chunk_raw, valid_in(chunk), pre);
+    c32 v[E];
+    f.template unpack<IO>(pre, v);
+    if constexpr (MODE != kModeCopy) f.template transform<FWD, MODE == kModeFFT>(v, false);
+    f.template store<IO>(out + chunk * chunk_raw, valid_in(chunk), v);
+    return;
+  }
   {
     const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
     f.template load<IO>(in + chunk * chunk_raw, valid_in(chunk), pre);
