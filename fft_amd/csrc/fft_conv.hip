@@ -190,12 +190,24 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_conv_tiles_kernel(const T*
   const BlockFFT<P> f(tw, lds);
   const long long tile0 = (long long)blockIdx.x * P::TPB;
 
+  // Points beyond the input read point 0 and are zeroed afterwards: the loads are unconditional, so all of a thread's
+  // E loads are in flight together (a load under a condition is a basic block of its own, closed by a wait).
   c32 v[E];
+  auto in_range = [&](int e, long long& idx) {
+    const long long t = tile0 + f.transform_in(e);
+    idx = t * valid + f.index_in(e);
+    return t < ntiles && idx < input_len;
+  };
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const long long t = tile0 + f.transform_in(e);
-    const long long idx = t * valid + f.index_in(e);
-    v[e] = (t < ntiles && idx < input_len) ? PointIO<T>::get(in + idx) : make_float2(0.f, 0.f);
+    long long idx;
+    const bool ok = in_range(e, idx);
+    v[e] = PointIO<T>::get(in + (ok ? idx : 0));
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    long long idx;
+    if (!in_range(e, idx)) v[e] = make_float2(0.f, 0.f);
   }
   f.template transform<true>(v, false);
 #pragma unroll

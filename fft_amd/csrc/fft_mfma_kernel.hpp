@@ -579,6 +579,12 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
 #pragma unroll
       for (int j = 0; j < 4; ++j) L[G][j] = __builtin_nontemporal_load(src + 256 * (4 * G + g) + 16 * j);
   }
+  // N = 8192: nothing moves across this line, so that every row load is out before the table loads below (fp16 x -> y
+  // 72.4-73.4 -> 74.4-74.7 % of 8 TB/s in an A/B of the two builds, bf16 level; the kernel also loses its 8 bytes of
+  // scratch). Not for N = 16384: there the scheduler, left alone, puts the tables between the rows and holds the
+  // last four rows back until the first tables have arrived, and that order measured 1-1.5 points FASTER for fp16
+  // (level for bf16) than all sixteen rows first.
+  if constexpr (R0 == 2) __builtin_amdgcn_sched_barrier(0);
 
   // ---- constants of the 4096-point passes
   T16 mat;
