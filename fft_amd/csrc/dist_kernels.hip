@@ -84,16 +84,24 @@ __global__ __launch_bounds__(256) void dist_permute_kernel(const float2* __restr
     const unsigned long long mask = (unsigned long long)(a.tw_n - 1);
     const unsigned long long p_first = (unsigned long long)(a.tw_p0 + a.tw_pi * (i0 + row0)) & mask;
     const unsigned long long p_step = (unsigned long long)(RS * a.tw_pi) & mask;
+    // Column j by per-lane look-ups (base and step: the table indices p q differ from lane to lane, so each is a
+    // gather); column j + 1 from it: q grows by tw_qj, and W^(p_first tw_qj), W^(p_step tw_qj) depend on the row alone
+    // -- the same table entry for every lane of a row, one cache line per wave-load instead of one per lane.
+    const unsigned long long qcol =
+        (unsigned long long)(a.tw_q0 + a.tw_qb1 * b1 + a.tw_qb2 * b2 + a.tw_qj * (j0 + lane2)) & mask;
+    const unsigned long long dq = (unsigned long long)a.tw_qj & mask;
+    c32 base[2], step[2];
+    base[0] = root(p_first * qcol);
+    step[0] = root(p_step * qcol);
+    base[1] = tfft::cmul(base[0], root(p_first * dq));
+    step[1] = tfft::cmul(step[0], root(p_step * dq));
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const unsigned long long q =
-          (unsigned long long)(a.tw_q0 + a.tw_qb1 * b1 + a.tw_qb2 * b2 + a.tw_qj * (j0 + lane2 + c)) & mask;
-      const c32 base = root(p_first * q);
       c32 pw[K];
-      tfft::twiddle_powers<K>(root(p_step * q), pw);
-      tw_k[c][0] = base;
+      tfft::twiddle_powers<K>(step[c], pw);
+      tw_k[c][0] = base[c];
 #pragma unroll
-      for (int k = 1; k < K; ++k) tw_k[c][k] = tfft::cmul(base, pw[k]);
+      for (int k = 1; k < K; ++k) tw_k[c][k] = tfft::cmul(base[c], pw[k]);
     }
   }
   auto twiddle = [&](c32 v, int k, int c) {
