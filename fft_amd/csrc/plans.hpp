@@ -186,7 +186,13 @@ KernelEntry make_mfma_entry() {
   e.lds_bytes = 4 * (mfma_out_words<R1>() + (DOUBLE ? Mfma4096::IMG : 0));
   // three workgroups per CU measured best for the resident form (two: 66 %, three: 72-75 %, four: 67 %)
   e.resident_per_cu = PERSIST ? 3 : 0;
+  // Runs of consecutive tiles per XCD. In place: 8 tiles (128 KiB), +0.5 ... 2 points over 16 in eight settled A/Bs
+  // and in bench.py alike (fp16 / bf16, N = 256 ... 4096: 79.5-80.2 -> 81.4-82.0 %). x -> y stays at 16: runs of 8 won
+  // the interleaved A/Bs there too (+0.2 ... 1.5) but lost 2-3 points in bench.py's own process, whose two buffers
+  // lie elsewhere -- the rate of two streams depends on where they lie, and the longer run is the one that holds up
+  // either way. Runs of 32 and more are 2-6 points behind in both forms.
   e.xcd_log2 = 4;
+  e.xcd_log2_in_place = PERSIST ? 4 : 3;
   return e;
 }
 
@@ -200,7 +206,7 @@ void launch_mfma_repeat(const void* in, void* out, const float2* tw, long long b
   const long long tiles = (batch * R1 + 15) / 16;
   fft_mfma4096_kernel<T16, true, DOUBLE, DOUBLE ? 4 : 8, false, R1, INCR, true>
       <<<dim3((unsigned)tiles), dim3(Mfma4096::WG), 0, stream>>>(static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out),
-                                                                 tw, batch, 4, repeats, io_mask);
+                                                                 tw, batch, 3, repeats, io_mask);
 }
 template <class T16>
 bool launch_mfma_repeat_n(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats,
@@ -258,7 +264,11 @@ KernelEntry make_mfma_big_entry() {
   e.radix[1] = 4096;
   e.radix[2] = 1;
   e.lds_bytes = 4 * 2 * mfma_out_words<16>();
-  e.xcd_log2 = 4;
+  // runs of consecutive transforms per XCD, from settled interleaved A/Bs (50 + launches per variant): N = 16384 best
+  // at 16 (75.2 % x -> y; 4: 71 %, 8: 75.0, 32: 74, 128: 72-73); N = 8192 x -> y at 4 (+0.6 ... 1.6 points over 16
+  // in four A/Bs, fp16 and bf16; 2: -3), in place at 8 (+0.7 ... 1.6)
+  e.xcd_log2 = R0 == 2 ? 2 : 4;
+  e.xcd_log2_in_place = R0 == 2 ? 3 : 4;
   e.one_workgroup_per_transform = true;
   return e;
 }
