@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of two library builds (ab/old/libthunderfft_hip.so against the tree's) on the kernels outside the fp32 batched
-# sweep: 16-bit N = 8192 / 16384, multi-pass lengths, the overlap-save convolution binary.
+# sweep: 16-bit N = 8192 / 16384, multi-pass lengths, the overlap-save convolution binary. Make the old build first:
+#   git stash (or git worktree add /tmp/old <commit>), make -j lib there, copy its fft_amd/lib/libthunderfft_hip.so to
+#   ab/old/libthunderfft_hip.so and to ab/libthunderfft_hip_old.so (ab/ is git-ignored and travels with gpurun).
 set -u
 for dt in fp16 bf16; do
   timeout -k 10 300 python tools/gpu_lib_ab.py --dtype $dt --lengths 4096,8192,16384 --groups 10 --burst 10 --passes 2 2>&1 | grep -v amdgpu.ids || exit 1
