@@ -90,6 +90,11 @@ class FilterSpectra {
                         reinterpret_cast<hipfftComplex*>(spectra32_.get()), HIPFFT_FORWARD) != HIPFFT_SUCCESS)
         harness::die("hipfftExecC2C failed");
       harness::narrow(spectra32_.get(), spectra_.get(), spectra_.size());
+    } else if (opt_.plan == 0) {
+      // the library's own transform, default convolution kernel: transform and re-ordering in one kernel
+      harness::tfft_ok(tfft_conv_filter_spectra(TFFT_F16, kLen, taps16_.get(), permuted_.get(), D_, nullptr),
+                       "filter transform + layout");
+      return;
     } else {
       harness::tfft_ok(tfft_exec_c2c(TFFT_F16, kLen, 1, taps16_.get(), spectra_.get(), D_, nullptr), "filter transform");
     }

@@ -28,6 +28,7 @@ SYMBOLS = (
     "tfft_conv_exec_opt",
     "tfft_conv_filter_layout",
     "tfft_conv_filter_layout_opt",
+    "tfft_conv_filter_spectra",
     "tfft_conv_forget_layout",
     "tfft_conv_tiles_exec",
     "tfft_get_twiddle_table",
@@ -117,6 +118,7 @@ def load():
     lib.tfft_dist_radix.argtypes = [vp, vp, ctypes.POINTER(DistRadixArgs), vp, i, vp]
     lib.tfft_conv_exec.argtypes = [i, i, i, vp, vp, vp, i, i, vp]
     lib.tfft_conv_filter_layout.argtypes = [i, i, vp, vp, i, vp]
+    lib.tfft_conv_filter_spectra.argtypes = [i, i, vp, vp, i, vp]
     lib.tfft_conv_forget_layout.argtypes = [vp, ctypes.c_ulonglong]
     lib.tfft_conv_tiles_exec.argtypes = [i, i, vp, vp, vp, ll, ll, i, vp]
     lib.tfft_get_twiddle_table.argtypes = [i, i, ctypes.POINTER(vp)]

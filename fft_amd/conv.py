@@ -48,9 +48,25 @@ def filter_spectra(h_time, N, stream=None, options=None):
     padded = torch.zeros(D, N, 2, dtype=h_time.dtype, device=h_time.device)
     padded[:, :K] = h_time
     ThunderFFTInitialize(h_time.dtype, N)
+    if not options and h_time.dtype == torch.float16:
+        # the default (matrix-core) kernel: transform and re-ordering in one kernel (tfft_conv_filter_spectra)
+        return filter_spectra_fused(padded, N, stream)
     spec = torch.empty_like(padded)
     ThunderFFT_global(padded, spec, D, N, True, stream)
     return filter_layout(spec, N, stream, options)
+
+
+def filter_spectra_fused(padded, N, stream=None):
+    """Zero-padded taps [D, N, 2] -> register-order spectra in one kernel (tfft_conv_filter_spectra): bit for bit
+    ThunderFFT_global followed by filter_layout. fp16, N = 4096 (ThunderFFTError UNSUPPORTED otherwise)."""
+    if not (padded.is_cuda and padded.is_contiguous()) or padded.shape[-2:] != (N, 2):
+        raise ThunderFFTError(3, "filter_spectra_fused needs a contiguous device tensor [D, N, 2]")
+    D = padded.numel() // (2 * N)
+    out = torch.empty_like(padded)
+    with torch.cuda.device(padded.device):
+        _check(_lib.load().tfft_conv_filter_spectra(dtype_code(padded.dtype), int(N), padded.data_ptr(), out.data_ptr(),
+                                                    int(D), _stream(padded, stream)))
+    return out
 
 
 def fft_conv(x, h_perm, N, kind=CONV_COMPLEX, out=None, stream=None, options=None):

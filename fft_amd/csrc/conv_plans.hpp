@@ -16,10 +16,16 @@ struct ConvEntry {
                  hipStream_t stream);
   // hp <- h: natural-order spectra [D][n] to register order
   void (*layout)(const void* h, void* hp, int D, hipStream_t stream);
+  // hp <- DFT_n(taps): transform and re-ordering in one kernel, where the plan has it (else null)
+  void (*spectra)(const void* taps, void* hp, const float2* tw, int D, hipStream_t stream) = nullptr;
   int n, threads, points_per_thread, lds_bytes;
   int layout_id;  // which register order `layout` writes and `launch` reads (kConvLayout*)
 };
 enum : int { kConvLayoutValu = 1, kConvLayoutMfma = 2 };
+
+// The default N = 4096 matrix-core kernel of fp16 storage with its result in the matrix-core convolution's filter
+// order (inst_f16.hip): `count` forward transforms [count][4096] -> [count][4][256] 16-byte entries.
+void launch_conv_spectra_f16(const void* in, void* out, const float2* tw, long long count, hipStream_t s);
 
 // plan 0: the default kernel of (dtype, n, kind); plan 3: the fp32-VALU kernel where the default runs on the
 // matrix cores (fp16 storage). The two read the permuted filters in different orders (layout_id).

@@ -364,6 +364,9 @@ bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
     out->lds_bytes = 4 * (Mfma4096::OUT_IMG + Mfma4096::IMG);
     out->layout = &launch_layout_mfma;
     out->layout_id = kConvLayoutMfma;
+    out->spectra = [](const void* taps, void* hp, const float2* tw, int D, hipStream_t stream) {
+      launch_conv_spectra_f16(taps, hp, tw, D, stream);
+    };
     // plan 0: the staged (LDS-DMA) form with RUN chosen from the problem size; 4: one workgroup per item (the
     // resident grid of grid_blocks_per_cu belongs to it); 5, 6: the staged form with RUN = 2 / 8 whatever the size
     if (plan == 5) return conv_mfma_dma_entry<2>(kind, out);

@@ -326,13 +326,17 @@ constexpr int mfma_out_words() {
 // REPEAT (measurement builds only): the three passes run `repeats` times on the tile, the natural-order output
 // image of one round being read back as the rows of the next, so that the launch prices the on-chip work
 // (registers -> three passes -> LDS image -> registers) without more HBM traffic. Values overflow; timing only.
+// CONVOUT (N = 4096, one workgroup per transform): the result leaves in the order the fused convolution reads its
+// filter spectra -- 16-byte entry [transform][t][tid] = X[i + 16 (4w + t) + 256 (4g + r)], r = 0..3, which is exactly
+// what a lane holds after pass 3 -- instead of natural order: the filter transform and its re-ordering in one kernel.
 template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false,
-          bool REPEAT = false>
+          bool REPEAT = false, bool CONVOUT = false>
 __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* in, u32x4_t* out,  // in and out may alias (in-place calls)
                                                                      const float2* __restrict__ tw, long long batch,
                                                                      int xcd_log2, unsigned repeats = 1,
                                                                      unsigned io_mask = 3) {
   static_assert(!REPEAT || !PERSIST, "the repeat build is a one-shot kernel");
+  static_assert(!CONVOUT || (R1 == 16 && !PERSIST && !REPEAT), "the filter order is that of one 4096-point transform");
   // measurement build only: bit 0 = load the tile's rows (else start from constants), bit 1 = store the result;
   // run-time flags, so that the rest of the kernel is compiled as it stands
   const bool do_loads = !REPEAT || (io_mask & 1u), do_stores = !REPEAT || (io_mask & 2u);
@@ -497,6 +501,18 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   // lane holds X of sub-transform s = i at k2 = 4w + t, k3 = 4g + r: point
   // p = (i / R1) N + (i mod R1) + R1 (k2 + 16 k3) of the tile
   // (the padding of mfma_out_slot is the same for a lane's 16 values, or grows by 4 per r when R1 = 16)
+  if constexpr (CONVOUT) {
+    u32x4_t* dst = out + tile * 1024 + tid;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      mfma_f4 cr, ci;
+      mat.dft16(frag[t], cr, ci);
+      __builtin_nontemporal_store(
+          u32x4_t{T16::pack(cr[0], ci[0]), T16::pack(cr[1], ci[1]), T16::pack(cr[2], ci[2]), T16::pack(cr[3], ci[3])},
+          dst + 256 * t);
+    }
+    return;
+  }
   const int slot0 = mfma_out_slot<R1>((i / R1) * (256 * R1) + (i % R1) + R1 * (4 * w) + 16 * R1 * (4 * g));
   constexpr int R_STEP = 16 * R1 + (R1 == 16 ? 4 : 0);
   unsigned last[4][4];

@@ -1,4 +1,5 @@
 // fp16 storage (fp32 arithmetic), every length.
+#include "conv_plans.hpp"
 #include "inst_common.hpp"
 namespace tfft {
 // 16-bit storage halves the bytes per workgroup; where the A/B of the fp32 plans came out the other way
@@ -47,5 +48,11 @@ bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
 bool launch_repeat_f16(int n, const void* in, void* out, const float2* tw, long long batch, unsigned repeats, unsigned io_mask,
                         hipStream_t s) {
   return launch_mfma_repeat_n<MfmaF16>(n, in, out, tw, batch, repeats, io_mask, s);
+}
+void launch_conv_spectra_f16(const void* in, void* out, const float2* tw, long long count, hipStream_t s) {
+  // the default kernel of fp16 N = 4096 (two LDS images, incremental pass-1 twiddles), forward, filter order out
+  fft_mfma4096_kernel<MfmaF16, true, true, 4, false, 16, true, false, true>
+      <<<dim3((unsigned)count), dim3(Mfma4096::WG), 0, s>>>(static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw,
+                                                            count, 4);
 }
 }  // namespace tfft

@@ -812,6 +812,42 @@ int tfft_conv_filter_layout_opt(int dtype, int n, const void* d_h_freq, void* d_
   return TFFT_OK;
 }
 
+int tfft_conv_filter_spectra(int dtype, int n, const void* d_taps, void* d_h_perm, int D, void* stream) {
+  tfft::ConvEntry e;
+  if (int rc = conv_common("tfft_conv_filter_spectra", dtype, n, TFFT_CONV_COMPLEX, 0, &e)) return rc;
+  if (!e.spectra)
+    return fail(TFFT_ERR_UNSUPPORTED,
+                "tfft_conv_filter_spectra: %s n=%d has no one-kernel form: call tfft_exec_c2c and tfft_conv_filter_layout",
+                dtype_name(dtype), n);
+  if (D < 0) return fail(TFFT_ERR_INVALID, "tfft_conv_filter_spectra: negative D");
+  if (D == 0) return TFFT_OK;
+  if (!d_taps || !d_h_perm || d_taps == d_h_perm)
+    return fail(TFFT_ERR_INVALID, "tfft_conv_filter_spectra: null or aliased device pointers");
+  if ((reinterpret_cast<uintptr_t>(d_taps) | reinterpret_cast<uintptr_t>(d_h_perm)) & 15u)
+    return fail(TFFT_ERR_INVALID, "tfft_conv_filter_spectra: buffers must be 16-byte aligned");
+  int dev = 0;
+  TFFT_HIP(hipGetDevice(&dev));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    ReadLock lock(g_mu);  // held from the look-up to the launch, like every transform call
+    auto it = g_plans.find(std::make_tuple(dev, dtype, n));
+    if (it == g_plans.end())
+      return fail(TFFT_ERR_NOT_INITIALIZED, "tfft_conv_filter_spectra: call tfft_initialize(%s, %d) on device %d first",
+                  dtype_name(dtype), n, dev);
+    e.spectra(d_taps, d_h_perm, it->second.tw, D, s);
+    TFFT_HIP(hipGetLastError());
+  }
+  {
+    WriteLock lock(g_mu);
+    const char* lo = static_cast<const char*>(d_h_perm);
+    const char* hi = lo + (size_t)D * n * 4;
+    forget_conv_layout(dev, lo, hi);
+    if (g_conv_tags.size() >= kMaxConvTags) g_conv_tags.erase(g_conv_tags.begin());
+    g_conv_tags.push_back(ConvLayoutTag{dev, dtype, lo, hi, e.layout_id});
+  }
+  return finish_launch(s);
+}
+
 int tfft_conv_forget_layout(const void* d_buffer, unsigned long long bytes) {
   if (!d_buffer) return fail(TFFT_ERR_INVALID, "tfft_conv_forget_layout: null pointer");
   int dev = 0;

@@ -248,6 +248,14 @@ int tfft_conv_exec(int dtype, int n, int kind, const void* d_x, const void* d_h_
  * alias d_h_freq. */
 int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_perm, int D, void* stream);
 
+/* The two steps of the reference's filter_fft_once (sample/conv1d/conv1d_fullfft_l4096_thunder.cu:412-426: forward
+ * transform of the zero-padded taps, then permute_filter_layout4096) in ONE kernel: d_h_perm <- DFT_n(d_taps) in the
+ * order tfft_conv_exec reads, bit for bit what tfft_exec_c2c followed by tfft_conv_filter_layout writes. d_taps:
+ * D zero-padded filters [D][n] interleaved complex of `dtype`; must not alias d_h_perm. Exists where the default
+ * convolution kernel runs on the matrix cores (fp16, n = 4096); TFFT_ERR_UNSUPPORTED otherwise (use the two calls).
+ * Needs tfft_initialize(dtype, n). Asynchronous on `stream`; allocates nothing. */
+int tfft_conv_filter_spectra(int dtype, int n, const void* d_taps, void* d_h_perm, int D, void* stream);
+
 /* The two convolution calls with per-call options (opt == NULL: exactly the calls above). The matrix-core kernels
  * (plans 0, 4, 5, 6) and the fp32-VALU kernels (plan 3) read the permuted filters in different orders: the library remembers which order each
  * d_h_perm buffer was last written in and tfft_conv_exec(_opt) returns TFFT_ERR_INVALID when asked to read a

@@ -111,6 +111,32 @@ def test_signal_uses_filter_index_mod_D(oracle_mod):
         assert np.linalg.norm(y[:, d] - want) / np.linalg.norm(want) < 3e-6, d
 
 
+def test_filter_spectra_in_one_kernel_equals_the_two_calls():
+    """tfft_conv_filter_spectra (forward transform of the zero-padded taps straight into the order the fused kernel
+    reads) against tfft_exec_c2c followed by tfft_conv_filter_layout: bit for bit, for one filter, an odd count and
+    many; the convolution accepts the buffer as one the library laid out; fp32 has no one-kernel form."""
+    g = torch.Generator(device="cuda").manual_seed(77)
+    fft_amd.ThunderFFTInitialize("fp16", N)
+    for D in (1, 7, 768):
+        taps = torch.zeros(D, N, 2, device="cuda", dtype=torch.float16)
+        taps[:, :63] = ((torch.rand(D, 63, 2, device="cuda", generator=g) * 2 - 1) / N).to(torch.float16)
+        spec = torch.empty_like(taps)
+        fft_amd.ThunderFFT_global(taps, spec, D, N, True)
+        want = conv.filter_layout(spec, N)
+        got = conv.filter_spectra_fused(taps, N)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), D
+        x = torch.rand(2, D, N, device="cuda", generator=g).to(torch.float16)
+        y = conv.fft_conv(x, got, N, conv.CONV_REAL_IN)  # the layout record of `got` is the matrix-core kernels'
+        assert torch.equal(y, conv.fft_conv(x, want, N, conv.CONV_REAL_IN))
+    with pytest.raises(fft_amd.ThunderFFTError) as e:
+        conv.filter_spectra_fused(torch.zeros(2, N, 2, device="cuda"), N)
+    assert e.value.code == 1  # TFFT_ERR_UNSUPPORTED
+    with pytest.raises(fft_amd.ThunderFFTError) as e:  # a buffer laid out for the matrix-core kernels, read by the VALU one
+        conv.fft_conv(x, got, N, conv.CONV_REAL_IN, options={"plan": 3})
+    assert e.value.code == 3
+
+
 def test_filter_layout_is_a_permutation():
     D = 3
     h = torch.arange(D * N * 2, dtype=torch.float32, device="cuda").reshape(D, N, 2).contiguous()
