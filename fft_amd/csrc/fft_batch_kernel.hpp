@@ -47,33 +47,33 @@ __global__ __launch_bounds__(P::WG, P::MINW) void fft_lds_kernel(const typename 
     f.template unpack<IO>(pre, v);
     if constexpr (MODE != kModeCopy) f.template transform<FWD, MODE == kModeFFT>(v, false);
     f.template store<IO>(out + chunk * chunk_raw, valid_in(chunk), v);
-    return;
-  }
-  {
-    const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
-    f.template load<IO>(in + chunk * chunk_raw, valid_in(chunk), pre);
-  }
-  for (;;) {
-    const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
-    const long long next = unit + gridDim.x;
-    const bool more = next < nchunks;  // uniform: every thread of the workgroup walks the same chunks
-    c32 v[E];
-    f.template unpack<IO>(pre, v);
-    if constexpr (P::PREFETCH) {
-      if (more) {
-        const long long nc = xcd_chunk(next, nchunks, xcd_log2);
+  } else {
+    {
+      const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
+      f.template load<IO>(in + chunk * chunk_raw, valid_in(chunk), pre);
+    }
+    for (;;) {
+      const long long chunk = xcd_chunk(unit, nchunks, xcd_log2);
+      const long long next = unit + gridDim.x;
+      const bool more = next < nchunks;  // uniform: every thread of the workgroup walks the same chunks
+      c32 v[E];
+      f.template unpack<IO>(pre, v);
+      if constexpr (P::PREFETCH) {
+        if (more) {
+          const long long nc = xcd_chunk(next, nchunks, xcd_log2);
+          f.template load<IO>(in + nc * chunk_raw, valid_in(nc), pre);
+        }
+      }
+      if constexpr (MODE != kModeCopy) f.template transform<FWD, MODE == kModeFFT>(v, false);
+      f.template store<IO>(out + chunk * chunk_raw, valid_in(chunk), v);
+      if (!more) break;
+      // the exchange buffer is reused by the next chunk of this workgroup
+      if constexpr (MODE == kModeFFT) __syncthreads();
+      unit = next;
+      if constexpr (!P::PREFETCH) {
+        const long long nc = xcd_chunk(unit, nchunks, xcd_log2);
         f.template load<IO>(in + nc * chunk_raw, valid_in(nc), pre);
       }
-    }
-    if constexpr (MODE != kModeCopy) f.template transform<FWD, MODE == kModeFFT>(v, false);
-    f.template store<IO>(out + chunk * chunk_raw, valid_in(chunk), v);
-    if (!more) break;
-    // the exchange buffer is reused by the next chunk of this workgroup
-    if constexpr (MODE == kModeFFT) __syncthreads();
-    unit = next;
-    if constexpr (!P::PREFETCH) {
-      const long long nc = xcd_chunk(unit, nchunks, xcd_log2);
-      f.template load<IO>(in + nc * chunk_raw, valid_in(nc), pre);
     }
   }
 }
