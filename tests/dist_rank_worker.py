@@ -1,5 +1,5 @@
 """One rank of the distributed transform on a real process group with DEVICE tensors: started by
-tests/test_distributed_ranks_gpu.py under torch.distributed.run (RANK / WORLD_SIZE / MASTER_* from the environment).
+tests/test_zy_distributed_ranks_gpu.py under torch.distributed.run (RANK / WORLD_SIZE / MASTER_* from the environment).
 
     python dist_rank_worker.py <backend> <log2 n> <out_dir>
 
