@@ -7,7 +7,7 @@ run() { tag=$1; shift; PROF_DIR=prof_$tag BENCH_ARGS="$*" bash tools/gpu_profile
 mkdir -p gpurun_out
 run fp32_4096
 run fp32_8192 --fft-len 8192
-run fp32_16384 --fft-len 16384
+TRACE_STEPS=100 TRACE_WARMUP=50 run fp32_16384 --fft-len 16384
 TRACE_STEPS=100 TRACE_WARMUP=50 run fp16_4096 --dtype fp16
 TRACE_STEPS=100 TRACE_WARMUP=50 run bf16_4096 --dtype bf16
 run fp32_2p26 --fft-len 67108864 --batch 1
