@@ -3,8 +3,9 @@
 // one read and one write of every point, 16-byte accesses. The reference has no distributed or multi-GPU
 // code (single cudaSetDevice per sample, thunderfft/sample/fft1d/main.cu:80); there is nothing to cite.
 //
-//   tfft_dist_permute : batched 2-D copy through a 64 x 64 LDS tile, transposing or not, optionally times the
-//                       four-step twiddle W_n^(p q) with p, q affine in the element's indices (two-level table)
+//   tfft_dist_permute : batched 2-D copy, transposing (through an LDS tile of 4096 points: 64 x 64, 128 x 32 or
+//                       32 x 128) or not (row segments straight through registers), optionally times the four-step
+//                       twiddle W_n^(p q) with p, q affine in the element's indices (two-level table)
 //   tfft_dist_radix   : radix-P butterfly across the P chunks a rank holds after an exchange, times the
 //                       twiddle W_M^(t k) -- the step that turns "P chunks of rows of length T" into P batches
 //                       of rows whose length-T transforms finish a length-M = P T transform
