@@ -9,6 +9,8 @@
 // (the reference multiplies and accumulates in fp16), and consecutive workgroups share a filter
 // (block -> (d, b) with b fastest), so that a filter spectrum is read from HBM once and then
 // served by L2 to the B signals that use it.
+#include <cmath>
+
 #include "conv_plans.hpp"
 #include "fft_block.hpp"
 #include "fft_conv_mfma.hpp"
@@ -300,10 +302,34 @@ void launch_conv_mfma(const void* x, const void* hp, void* y, const float2* tw, 
   }
 }
 
+// How many work items of one filter a workgroup of the staged kernel takes (8, 4 or 2), or 0 for the
+// one-workgroup-per-item kernel. A run costs its items plus about a quarter of an item for the 48 KiB of tables and
+// filter it reads before its first signal, so long runs win while they still fill the `slots` resident workgroups
+// (three per CU) about evenly: the estimate is (workgroups / slots, rounded up to whole rounds below four of them)
+// x (items per run + 1/4), against 1.6 per item for the kernel that overlaps nothing. It names the fastest run length,
+// or one within 1 % of it, on all thirteen shapes it was checked on (B = 2 ... 128 real pairs, D = 24 ... 768).
+inline int conv_run_length(unsigned nb, unsigned D, unsigned slots) {
+  auto rounds = [&](unsigned long long groups) {
+    const double r = (double)groups / (double)slots;
+    return r >= 4.0 ? r : std::ceil(r);
+  };
+  int run = 0;
+  double best = rounds((unsigned long long)nb * D) * 1.6;
+  if (nb < 2) return 0;
+  for (const unsigned r : {2u, 4u, 8u}) {
+    const unsigned long long groups = (unsigned long long)((nb + r - 1) / r) * D;
+    const double cost = rounds(groups) * ((double)(r < nb ? r : nb) + 0.25);
+    if (cost <= best) {
+      best = cost;
+      run = (int)r;
+    }
+  }
+  return run;
+}
+
 // The default form for fp16 storage: one workgroup per run of RUN work items of one filter, the next item's signal
-// travelling into LDS under the current item's passes (fft_conv_mfma4096_dma_kernel). RUN is the longest of 8, 4, 2
-// that still leaves six workgroups per resident slot (three slots per CU); problems too small for that, and calls
-// that ask for the resident grid (per_cu > 0), take the one-workgroup-per-item kernel.
+// travelling into LDS under the current item's passes (fft_conv_mfma4096_dma_kernel), RUN from conv_run_length;
+// calls that ask for the resident grid (per_cu > 0) take the one-workgroup-per-item kernel.
 template <int KIND>
 void launch_conv_mfma_default(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int per_cu,
                               hipStream_t stream) {
@@ -314,36 +340,33 @@ void launch_conv_mfma_default(const void* x, const void* hp, void* y, const floa
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
-  const unsigned long long want = 6ull * 3ull * (unsigned)cus;  // workgroups
-  auto groups = [&](unsigned run) { return (unsigned long long)((nb + run - 1) / run) * (unsigned)D; };
+  const int run = per_cu > 0 ? 0 : conv_run_length(nb, (unsigned)D, 3u * (unsigned)cus);
+  auto groups = [&](unsigned r) { return (unsigned)(((nb + r - 1) / r) * (unsigned)D); };
   const u32x4_t* h = static_cast<const u32x4_t*>(hp);
-  if (per_cu > 0 || groups(2) < want) {
-    launch_conv_mfma<KIND>(x, hp, y, tw, B, D, per_cu, stream);
-  } else if (groups(8) >= want) {
-    fft_conv_mfma4096_dma_kernel<KIND, 8><<<dim3((unsigned)groups(8)), dim3(256), 0, stream>>>(x, h, y, tw, B, D);
-  } else if (groups(4) >= want) {
-    fft_conv_mfma4096_dma_kernel<KIND, 4><<<dim3((unsigned)groups(4)), dim3(256), 0, stream>>>(x, h, y, tw, B, D);
-  } else {
-    fft_conv_mfma4096_dma_kernel<KIND, 2><<<dim3((unsigned)groups(2)), dim3(256), 0, stream>>>(x, h, y, tw, B, D);
+  switch (run) {
+    case 8: fft_conv_mfma4096_dma_kernel<KIND, 8><<<dim3(groups(8)), dim3(256), 0, stream>>>(x, h, y, tw, B, D); break;
+    case 4: fft_conv_mfma4096_dma_kernel<KIND, 4><<<dim3(groups(4)), dim3(256), 0, stream>>>(x, h, y, tw, B, D); break;
+    case 2: fft_conv_mfma4096_dma_kernel<KIND, 2><<<dim3(groups(2)), dim3(256), 0, stream>>>(x, h, y, tw, B, D); break;
+    default: launch_conv_mfma<KIND>(x, hp, y, tw, B, D, per_cu, stream); break;
   }
 }
 
 // The staged form whatever the problem size (tests: every RUN on small shapes).
-template <int KIND, int RUN>
+template <int KIND, int RUN, bool PRIV>
 void launch_conv_mfma_dma(const void* x, const void* hp, void* y, const float2* tw, int B, int D, int per_cu,
                           hipStream_t stream) {
   (void)per_cu;
   const unsigned nb = (KIND == kConvMfmaRealPair) ? ((unsigned)B + 1u) / 2u : (unsigned)B;
-  fft_conv_mfma4096_dma_kernel<KIND, RUN><<<dim3(((nb + RUN - 1) / RUN) * (unsigned)D), dim3(256), 0, stream>>>(
+  fft_conv_mfma4096_dma_kernel<KIND, RUN, PRIV><<<dim3(((nb + RUN - 1) / RUN) * (unsigned)D), dim3(256), 0, stream>>>(
       x, static_cast<const u32x4_t*>(hp), y, tw, B, D);
 }
 
-template <int RUN>
+template <int RUN, bool PRIV = false>
 bool conv_mfma_dma_entry(int kind, ConvEntry* out) {
   switch (kind) {
-    case kConvComplex: out->launch = &launch_conv_mfma_dma<kConvMfmaComplex, RUN>; return true;
-    case kConvRealIn: out->launch = &launch_conv_mfma_dma<kConvMfmaRealIn, RUN>; return true;
-    case kConvRealInOut: out->launch = &launch_conv_mfma_dma<kConvMfmaRealPair, RUN>; return true;
+    case kConvComplex: out->launch = &launch_conv_mfma_dma<kConvMfmaComplex, RUN, PRIV>; return true;
+    case kConvRealIn: out->launch = &launch_conv_mfma_dma<kConvMfmaRealIn, RUN, PRIV>; return true;
+    case kConvRealInOut: out->launch = &launch_conv_mfma_dma<kConvMfmaRealPair, RUN, PRIV>; return true;
     default: return false;
   }
 }
@@ -354,7 +377,7 @@ void launch_layout_mfma(const void* h, void* hp, int D, hipStream_t stream) {
 }
 
 bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
-  if (n != 4096 || (plan != 0 && plan != 3 && !(dtype == TFFT_F16 && plan >= 4 && plan <= 6))) return false;
+  if (n != 4096 || (plan != 0 && plan != 3 && !(dtype == TFFT_F16 && plan >= 4 && plan <= 7))) return false;
   out->layout_id = kConvLayoutValu;
   if (dtype == TFFT_F16 && plan != 3) {
     // fp16 storage: both transforms on the matrix cores (fft_conv_mfma.hpp)
@@ -368,9 +391,12 @@ bool lookup_conv(int dtype, int n, int kind, int plan, ConvEntry* out) {
       launch_conv_spectra_f16(taps, hp, tw, D, stream);
     };
     // plan 0: the staged (LDS-DMA) form with RUN chosen from the problem size; 4: one workgroup per item (the
-    // resident grid of grid_blocks_per_cu belongs to it); 5, 6: the staged form with RUN = 2 / 8 whatever the size
+    // resident grid of grid_blocks_per_cu belongs to it); 5, 6: the staged form with RUN = 2 / 8 whatever the size;
     if (plan == 5) return conv_mfma_dma_entry<2>(kind, out);
     if (plan == 6) return conv_mfma_dma_entry<8>(kind, out);
+    // 7: runs of 4 with wave-private staging and alternating images (two barriers fewer per item; measured level
+    // with the shared staging area, kept for A/B)
+    if (plan == 7) return conv_mfma_dma_entry<4, true>(kind, out);
     if (plan == 0) {
       switch (kind) {
         case kConvComplex: out->launch = &launch_conv_mfma_default<kConvMfmaComplex>; return true;

@@ -11,43 +11,48 @@
 // exactly the B fragment of the inverse's first pass. The product with H (stored in that lane
 // order) is rounded to fp16 and fed straight back into the matrix cores.
 //
-// Pass-1 twiddles W_4096^(k1 c) are built incrementally, W^(k1 (c0 + s)) = W^(k1 c0) * (W^(k1 q))^s,
-// from 4 start values per lane and 4 step values per lane group, so that the tables a workgroup
-// reads stay small (16 KiB for both column maps) instead of one value per point.
+// Pass-1 twiddles W_4096^(k1 c) come from a table of packed fp16 values in lane order (16 per lane and column
+// map, 32 KiB for both maps, read once per workgroup and kept in registers) and are applied with the packed fp16
+// product the pass-2 twiddles use (3 instructions per value, rounding included). The fp32 form they replace -- 4
+// start and 4 step values per lane, W^(k1 (c0 + s)) = W^(k1 c0) (W^(k1 q))^s, 16 KiB of tables -- cost 4 + 1
+// instructions per value plus 12 complex products per pass for the chains: about 120 of the 490 VALU instructions
+// per wave and signal, in a kernel whose on-chip work alone takes longer than its HBM traffic (with the loads or the
+// stores compiled out it ran at 87 % and 82 % of its full time, with neither at 78 %). Rounding the twiddles to fp16
+// moves the result's error against an fp64 convolution from 5.5e-4 to 5.6e-4 (relative L2).
 #pragma once
 #include "fft_mfma_kernel.hpp"
 
 namespace tfft {
 
 struct ConvMfma4096 {
-  // float2 entries appended after Mfma4096's tables
-  static constexpr int TABLE = 2 * (512 + 512 + 8 + 8);
+  // float2-sized entries appended after Mfma4096's tables: 2 maps x 4 fragments x 256 lanes x 4 packed fp16 pairs
+  static constexpr int TABLE = 2 * 4 * 256 * 4 / 2;
   static constexpr int OFFSET = Mfma4096::N + Mfma4096::TABLES;
 };
 
-// Host side. float4 units: start_global [h][tid] (512), start_chain [h][tid] (512), step_global [h][g] (8),
-// step_chain [h][g] (8); entry = { W^(e(k1)), W^(e(k1 + 1)) } with k1 = 4g + 2h, forward sign (cos, -sin).
+// Host side. 16-byte entry [m][s][tid] = W^(k1 c) as fp16 (cos, -sin) for k1 = 4g + r, r = 0..3, with
+// tid = 64w + 16g + i and column c = 64w + 4i + s (map m = 0: fragments straight from the signal's rows) or
+// c = 16 (4w + s) + i (map m = 1: fragments that are the previous transform's output registers).
 inline void conv_mfma4096_tables(float2* dst) {
-  auto w = [](long long e) {
-    const double a = -2.0 * M_PI * (double)(e & 4095) / 4096.0;
-    return make_float2((float)cos(a), (float)sin(a));
-  };
-  for (int h = 0; h < 2; ++h)
-    for (int tid = 0; tid < 256; ++tid) {
-      const int wv = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
-      for (int u = 0; u < 2; ++u) {
-        const int k1 = 4 * g + 2 * h + u;
-        dst[2 * (h * 256 + tid) + u] = w((long long)k1 * (64 * wv + 4 * i));        // columns 64w + 4i + j
-        dst[2 * (512 + h * 256 + tid) + u] = w((long long)k1 * (64 * wv + i));      // columns 16 (4w + t) + i
+  unsigned* out = reinterpret_cast<unsigned*>(dst);
+  for (int m = 0; m < 2; ++m)
+    for (int s = 0; s < 4; ++s)
+      for (int tid = 0; tid < 256; ++tid) {
+        const int wv = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
+        const int c = m == 0 ? 64 * wv + 4 * i + s : 16 * (4 * wv + s) + i;
+        for (int r = 0; r < 4; ++r) {
+          const double a = -2.0 * M_PI * (double)(((4 * g + r) * c) & 4095) / 4096.0;
+          out[((m * 4 + s) * 256 + tid) * 4 + r] =
+              (unsigned)mfma_host_half((float)cos(a)) | ((unsigned)mfma_host_half((float)sin(a)) << 16);
+        }
       }
-    }
-  for (int h = 0; h < 2; ++h)
-    for (int g = 0; g < 4; ++g)
-      for (int u = 0; u < 2; ++u) {
-        const int k1 = 4 * g + 2 * h + u;
-        dst[2 * (1024 + h * 4 + g) + u] = w(k1);                  // one column further
-        dst[2 * (1032 + h * 4 + g) + u] = w(16LL * k1);           // sixteen columns further
-      }
+}
+
+// This lane's pass-1 twiddles of column map `map` (see conv_mfma4096_tables).
+__device__ __forceinline__ void conv_mfma4096_load_tw1(const float2* tw, int map, int tid, u32x4_t (&tw1)[4]) {
+  const u32x4_t* tab = reinterpret_cast<const u32x4_t*>(tw + ConvMfma4096::OFFSET) + map * 1024 + tid;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) tw1[s] = tab[s * 256];
 }
 
 enum : int { kConvMfmaComplex = 0, kConvMfmaRealIn = 1, kConvMfmaRealPair = 2 };
@@ -72,12 +77,9 @@ struct MfmaDir {
 // Pass 1 on four fragments. CHAIN = false: fragment s holds column 64w + 4i + s (rows straight from
 // global memory); CHAIN = true: column 16 (4w + s) + i (the previous transform's output registers).
 template <bool FWD, bool CHAIN>
-__device__ __forceinline__ void mfma_pass1(const MfmaDir<FWD>& d, const u32x4_t (&packed)[4], const c32 (&start)[4],
-                                           const c32 (&step)[4], unsigned* img, int w, int g, int i) {
+__device__ __forceinline__ void mfma_pass1(const MfmaDir<FWD>& d, const u32x4_t (&packed)[4], const u32x4_t (&tw1)[4],
+                                           unsigned* img, int w, int g, int i) {
   const mfma_f4 zero = {0.f, 0.f, 0.f, 0.f};
-  c32 tw[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tw[r] = start[r];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const mfma_h8 b = __builtin_bit_cast(mfma_h8, packed[s]);
@@ -88,11 +90,10 @@ __device__ __forceinline__ void mfma_pass1(const MfmaDir<FWD>& d, const u32x4_t 
     const int n3 = CHAIN ? i : 4 * (i & 3) + s;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const c32 y = MfmaDir<FWD>::twiddle(cr[r], ci[r], tw[r]);
       const int row = (4 * g + r) * 16 + n3;
       const int rot = ((n3 >> 1) + g) & 3;
-      img[row * 16 + ((n2 + 4 * rot) & 15)] = pack_f16(y.x, y.y);
-      if (s < 3) tw[r] = cmul(tw[r], step[r]);
+      img[row * 16 + ((n2 + 4 * rot) & 15)] =
+          cmul_h2<!FWD>(pack_h2(cr[r], ci[r]), __builtin_bit_cast(h2_t, (unsigned)tw1[s][r]));
     }
   }
 }
@@ -217,22 +218,10 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
   Item cur = locate(idx);
   request_rows(cur);
 
-  // ---- the twiddle starts and steps, the matrix fragments
-  const float4* ctab = reinterpret_cast<const float4*>(tw + ConvMfma4096::OFFSET);
-  c32 start_g[4], start_c[4], step_g[4], step_c[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float4 a = ctab[h * 256 + tid], b = ctab[512 + h * 256 + tid];
-    const float4 p = ctab[1024 + h * 4 + g], q = ctab[1032 + h * 4 + g];
-    start_g[2 * h] = make_float2(a.x, a.y);
-    start_g[2 * h + 1] = make_float2(a.z, a.w);
-    start_c[2 * h] = make_float2(b.x, b.y);
-    start_c[2 * h + 1] = make_float2(b.z, b.w);
-    step_g[2 * h] = make_float2(p.x, p.y);
-    step_g[2 * h + 1] = make_float2(p.z, p.w);
-    step_c[2 * h] = make_float2(q.x, q.y);
-    step_c[2 * h + 1] = make_float2(q.z, q.w);
-  }
+  // ---- the pass-1 twiddles of both column maps, the matrix fragments
+  u32x4_t tw1_g[4], tw1_c[4];
+  conv_mfma4096_load_tw1(tw, 0, tid, tw1_g);
+  conv_mfma4096_load_tw1(tw, 1, tid, tw1_c);
   h2_t t2[4];
   {
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
@@ -275,7 +264,7 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
       nxt = locate(next);
       request_rows(nxt);
     }
-    mfma_pass1<true, false>(fwd, packed, start_g, step_g, img_a, w, g, i);
+    mfma_pass1<true, false>(fwd, packed, tw1_g, img_a, w, g, i);
     __syncthreads();
     mfma_pass2<true>(fwd, t2, img_a, img_b, w, g, i);
     __syncthreads();
@@ -291,7 +280,7 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
     }
 
     // ---- inverse transform (image a is free: every wave is past the barrier that followed its reads)
-    mfma_pass1<false, true>(inv, packed, start_c, step_c, img_a, w, g, i);
+    mfma_pass1<false, true>(inv, packed, tw1_c, img_a, w, g, i);
     __syncthreads();
     mfma_pass2<false>(inv, t2, img_a, img_b, w, g, i);
     __syncthreads();
@@ -347,12 +336,22 @@ __device__ __forceinline__ void lds_dma_16(const void* gsrc, unsigned lds_byte_a
 // until just before item k's stores), so that every workgroup keeps a load in flight under its own arithmetic.
 // LDS: two pass images + the staging area = 49 KiB, three workgroups per CU. The filter spectrum and all twiddle
 // constants stay in registers for the run.
-template <int KIND, int RUN>
+//
+// PRIV: every wave stages exactly the bytes its own lanes consume (its 64 columns of all 16 rows: 16 segments of
+// 256 bytes of a complex signal, 128 bytes of a real one), lane l fetching the 16 bytes lane l will read, so the
+// staging area needs no workgroup barrier on either side: a wave waits for its own loads, reads, and issues the next
+// item's. The two pass images trade places from item to item, so that an item's first pass writes the image whose
+// last readers (the previous item's third inverse pass) are already behind a barrier, and the barrier that kept the
+// output image's readers ahead of the next first pass goes as well: five barriers per item instead of seven, and a
+// wave may start the next item while the others still store this one.
+template <int KIND, int RUN, bool PRIV = false>
 __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const void* xv, const u32x4_t* __restrict__ hp,
                                                                        void* yv,  // xv and yv may alias
                                                                        const float2* __restrict__ tw, int B, int D) {
-  __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + Mfma4096::IMG];
-  __shared__ __attribute__((aligned(16))) unsigned stage[4096];  // one item's signal(s) as they lie in memory
+  constexpr int kImgB = PRIV ? Mfma4096::OUT_IMG : Mfma4096::IMG;  // PRIV: either image may hold the output
+  __shared__ __attribute__((aligned(16))) unsigned lds[Mfma4096::OUT_IMG + kImgB];
+  __shared__ __attribute__((aligned(16))) unsigned stage[4096];  // one item's signal(s): as they lie in memory, or
+                                                                 // (PRIV) 4 KiB per wave in its lanes' order
   unsigned* const img_a = lds;
   unsigned* const img_b = lds + Mfma4096::OUT_IMG;
   const int tid = threadIdx.x;
@@ -369,12 +368,29 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const voi
   auto first_signal = [&](int bq) { return (long long)((KIND == kConvMfmaRealPair) ? 2 * bq : bq) * D + d; };
   auto has_second = [&](int bq) { return (KIND == kConvMfmaRealPair) && (2 * bq + 1 < B); };
 
-  // wave w copies 1 KiB pieces: piece (round, w) of the staging area = bytes [4096 round + 1024 w, + 1024)
+  // wave w copies 1 KiB pieces: piece (round, w) of the staging area = bytes [4096 round + 1024 w, + 1024);
+  // PRIV: piece r of the wave's own 4 KiB = bytes [4096 w + 1024 r, + 1024)
   const unsigned stage_lds = (unsigned)(uintptr_t)stage;
-  const unsigned wave_piece = __builtin_amdgcn_readfirstlane(stage_lds + 1024u * (unsigned)w);
+  const unsigned wave_piece = __builtin_amdgcn_readfirstlane(stage_lds + (PRIV ? 4096u : 1024u) * (unsigned)w);
+  const int lane = tid & 63;
   auto start_dma = [&](int bq) {
     const long long s0 = first_signal(bq);
-    if constexpr (KIND == kConvMfmaComplex) {
+    if constexpr (PRIV && KIND == kConvMfmaComplex) {
+      // instruction r: rows 4r .. 4r + 3, 16 lanes (256 bytes) per row: lane (g, i) fetches what it reads as rows[r]
+      const u32x4_t* src = static_cast<const u32x4_t*>(xv) + s0 * 1024 + 16 * w + (lane >> 4) * 64 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds_dma_16(src + 256 * r, wave_piece + 1024u * r);
+    } else if constexpr (PRIV) {
+      // instruction r: rows 8r .. 8r + 7 of one real signal, 8 lanes (128 bytes) per row
+      const u32x4_t* src0 = static_cast<const u32x4_t*>(xv) + s0 * 512 + 8 * w + (lane >> 3) * 32 + (lane & 7);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) lds_dma_16(src0 + 256 * r, wave_piece + 1024u * r);
+      if (has_second(bq)) {  // uniform over the workgroup
+        const u32x4_t* src1 = src0 + (long long)D * 512;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) lds_dma_16(src1 + 256 * r, wave_piece + 2048u + 1024u * r);
+      }
+    } else if constexpr (KIND == kConvMfmaComplex) {
       const u32x4_t* src = static_cast<const u32x4_t*>(xv) + s0 * 1024 + tid;  // 16 KiB, linear
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds_dma_16(src + 256 * r, wave_piece + 4096u * r);
@@ -395,21 +411,9 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const voi
   u32x4_t hreg[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) hreg[t] = hp[(long long)d * 1024 + t * 256 + tid];
-  const float4* ctab = reinterpret_cast<const float4*>(tw + ConvMfma4096::OFFSET);
-  c32 start_g[4], start_c[4], step_g[4], step_c[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float4 a = ctab[h * 256 + tid], b = ctab[512 + h * 256 + tid];
-    const float4 p = ctab[1024 + h * 4 + g], q = ctab[1032 + h * 4 + g];
-    start_g[2 * h] = make_float2(a.x, a.y);
-    start_g[2 * h + 1] = make_float2(a.z, a.w);
-    start_c[2 * h] = make_float2(b.x, b.y);
-    start_c[2 * h + 1] = make_float2(b.z, b.w);
-    step_g[2 * h] = make_float2(p.x, p.y);
-    step_g[2 * h + 1] = make_float2(p.z, p.w);
-    step_c[2 * h] = make_float2(q.x, q.y);
-    step_c[2 * h + 1] = make_float2(q.z, q.w);
-  }
+  u32x4_t tw1_g[4], tw1_c[4];
+  conv_mfma4096_load_tw1(tw, 0, tid, tw1_g);
+  conv_mfma4096_load_tw1(tw, 1, tid, tw1_c);
   h2_t t2[4];
   {
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
@@ -426,30 +430,33 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const voi
 
   // the first item's signal: every wave waits for its own pieces (and for the table loads above), then all meet
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll 1
-  for (int bq = bq0; bq < bq1; ++bq) {
+  auto item = [&](int bq, unsigned* const img_a, unsigned* const img_b) __attribute__((always_inline)) {
     const long long s0 = first_signal(bq), s1 = s0 + D;
     const bool two = has_second(bq);
-    // the twiddle chains W^(k1 c0) (W^(k1 q))^s are rebuilt per item from their start values: hoisted out of this
-    // loop, their 24 powers per column map would be live for the whole run
+    // an opaque copy per item: without it the optimiser derives per-use forms of the 32 twiddle registers (halves
+    // splatted, signs flipped) outside the loop and keeps those alive for the whole run
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      start_g[r] = fresh<false>(start_g[r]);
-      start_c[r] = fresh<false>(start_c[r]);
-    }
-    __syncthreads();  // the staging area is complete (each wave waited for its pieces before arriving here)
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(tw1_g[s][r]), "+v"(tw1_c[s][r]));
+    // the staging area is complete (each wave waited for its pieces before arriving here); PRIV: a wave reads
+    // nothing but its own pieces
+    if constexpr (!PRIV) __syncthreads();
 
     // ---- this lane's rows 4G + g, columns 64w + 4i .. 4i + 3, out of the staging area
     u32x4_t rows[4];
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
       if constexpr (KIND == kConvMfmaComplex) {
-        rows[G] = *reinterpret_cast<const u32x4_t*>(&stage[4 * ((4 * G + g) * 64 + 16 * w + i)]);
+        rows[G] = *reinterpret_cast<const u32x4_t*>(
+            &stage[PRIV ? 1024 * w + 256 * G + 4 * lane : 4 * ((4 * G + g) * 64 + 16 * w + i)]);
       } else {
-        const int at = 2 * ((4 * G + g) * 64 + 16 * w + i);  // dword index of four real points
+        // dword index of four real points; the second signal of a pair lies kSecond dwords further
+        constexpr int kSecond = PRIV ? 512 : 2048;
+        const int at = PRIV ? 1024 * w + 128 * G + 2 * lane : 2 * ((4 * G + g) * 64 + 16 * w + i);
         const u32x2_t a = *reinterpret_cast<const u32x2_t*>(&stage[at]);
         u32x2_t c = {0u, 0u};
-        if (two) c = *reinterpret_cast<const u32x2_t*>(&stage[2048 + at]);
+        if (two) c = *reinterpret_cast<const u32x2_t*>(&stage[kSecond + at]);
         rows[G] = u32x4_t{(a.x & 0xffffu) | (c.x << 16), (a.x >> 16) | (c.x & 0xffff0000u),
                           (a.y & 0xffffu) | (c.y << 16), (a.y >> 16) | (c.y & 0xffff0000u)};
       }
@@ -468,11 +475,14 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const voi
       a2 = s[0]; a3 = s[1];
       packed[j] = u32x4_t{a0, a1, a2, a3};
     }
-    __syncthreads();  // every wave has its rows in registers: the staging area is free
+    // every wave has its rows in registers: the staging area is free (PRIV: this wave's reads of its own pieces
+    // have returned, which is all that its next loads can overwrite)
+    if constexpr (PRIV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
     if (bq + 1 < bq1) start_dma(bq + 1);
 
     // ---- forward transform, product, inverse transform
-    mfma_pass1<true, false>(fwd, packed, start_g, step_g, img_a, w, g, i);
+    mfma_pass1<true, false>(fwd, packed, tw1_g, img_a, w, g, i);
     __syncthreads();
     mfma_pass2<true>(fwd, t2, img_a, img_b, w, g, i);
     __syncthreads();
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const voi
       for (int r = 0; r < 4; ++r)
         packed[t][r] = cmul_h2<false>(pack_h2(xr[t][r], xi[t][r]), __builtin_bit_cast(h2_t, (unsigned)hreg[t][r]));
     }
-    mfma_pass1<false, true>(inv, packed, start_c, step_c, img_a, w, g, i);
+    mfma_pass1<false, true>(inv, packed, tw1_c, img_a, w, g, i);
     __syncthreads();
     mfma_pass2<false>(inv, t2, img_a, img_b, w, g, i);
     __syncthreads();
@@ -515,6 +525,17 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const voi
       } else {
         __builtin_nontemporal_store(v[q], static_cast<u32x4_t*>(yv) + s0 * 1024 + tid + 256 * q);
       }
+    }
+  };
+  if constexpr (!PRIV) {
+#pragma unroll 1
+    for (int bq = bq0; bq < bq1; ++bq) item(bq, img_a, img_b);
+  } else {
+#pragma unroll 1
+    for (int bq = bq0; bq < bq1; bq += 2) {
+      item(bq, img_a, img_b);
+      if (bq + 1 >= bq1) break;
+      item(bq + 1, img_b, img_a);
     }
   }
 }

@@ -100,7 +100,8 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *                        only, the 256-point sweeps only; same results bit for bit. For the convolution entry points (fp16 storage): 0 = one workgroup
  *                        per run of 2 ... 8 signals of one filter, the next signal travelling into LDS under the
  *                        current one's passes (small problems fall back to plan 4); 3 = the fp32-VALU kernels;
- *                        4 = one workgroup per signal; 5, 6 = the plan-0 kernel with runs of 2 / 8 whatever the size.
+ *                        4 = one workgroup per signal; 5, 6 = the plan-0 kernel with runs of 2 / 8 whatever the size;
+ *                        7 = runs of 4 with per-wave staging (two workgroup barriers fewer per signal).
  *   xcd_run_log2       : -1 = the kernel's default; L >= 0 = every XCD takes runs of 2^L consecutive chunks of
  *                        the batch (0 = chunk order equals launch order); results do not depend on it
  *   grid_blocks_per_cu : resident grid of value * CU count workgroups that walk the batch (0 = default: one
@@ -257,7 +258,7 @@ int tfft_conv_filter_layout(int dtype, int n, const void* d_h_freq, void* d_h_pe
 int tfft_conv_filter_spectra(int dtype, int n, const void* d_taps, void* d_h_perm, int D, void* stream);
 
 /* The two convolution calls with per-call options (opt == NULL: exactly the calls above). The matrix-core kernels
- * (plans 0, 4, 5, 6) and the fp32-VALU kernels (plan 3) read the permuted filters in different orders: the library remembers which order each
+ * (plans 0, 4, 5, 6, 7) and the fp32-VALU kernels (plan 3) read the permuted filters in different orders: the library remembers which order each
  * d_h_perm buffer was last written in and tfft_conv_exec(_opt) returns TFFT_ERR_INVALID when asked to read a
  * buffer with the other kernel. */
 int tfft_conv_exec_opt(int dtype, int n, int kind, const void* d_x, const void* d_h_perm, void* d_y, int B, int D,

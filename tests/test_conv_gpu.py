@@ -212,9 +212,11 @@ def test_valu_plan_and_filter_layout_mismatch(oracle_mod):
 def test_staged_kernel_matches_one_workgroup_per_signal(oracle_mod, kind):
     """fp16 storage: the default kernel (runs of signals per workgroup, the next signal landing in LDS by LDS-DMA
     under the current one's passes) does the same arithmetic as the one-workgroup-per-signal kernel (plan 4), so
-    the results are bit-identical -- for runs of 2 and 8 forced on small shapes (plans 5, 6), for batches that do
-    not fill the last run, for an odd number of real signals (a pair with one member), and at a shape large
-    enough for the default to pick the staged form itself. One shape is also checked against the oracle."""
+    the results are bit-identical -- for runs of 2 and 8 forced on small shapes (plans 5, 6), for runs of 4 with
+    every wave staging its own columns and the two pass images trading places from item to item (plan 7), for
+    batches that do not fill the last run (odd run lengths included), for an odd number of real signals (a pair
+    with one member), and at a shape large enough for the default to pick the staged form itself. One shape is
+    also checked against the oracle."""
     rng = np.random.default_rng(kind)
     for B, D in ((1, 3), (5, 2), (17, 3), (19, 5), (64, 96)):
         shape = (B, D, N, 2) if kind == conv.CONV_COMPLEX else (B, D, N)
@@ -224,7 +226,7 @@ def test_staged_kernel_matches_one_workgroup_per_signal(oracle_mod, kind):
         h = torch.from_numpy(taps).to("cuda").to(torch.float16)
         hp = conv.filter_spectra(h, N)
         want = conv.fft_conv(x, hp, N, kind, options={"plan": 4})
-        for plan in (0, 5, 6):
+        for plan in (0, 5, 6, 7):
             got = torch.full_like(want, float("nan"))
             conv.fft_conv(x, hp, N, kind, out=got, options={"plan": plan} if plan else None)
             torch.cuda.synchronize()
@@ -238,10 +240,11 @@ def test_staged_kernel_matches_one_workgroup_per_signal(oracle_mod, kind):
             assert oracle_mod.rel_l2(got.reshape(B * D, N), ref) <= 1e-2
     # in place (x and y alias): the next signal is fetched before the current one is stored, never the same bytes
     if kind == conv.CONV_COMPLEX:
-        y = x.clone()
-        conv.fft_conv(y, hp, N, kind, out=y, options={"plan": 6})
-        torch.cuda.synchronize()
-        assert torch.equal(y, conv.fft_conv(x, hp, N, kind, options={"plan": 4}))
+        for plan in (6, 7):
+            y = x.clone()
+            conv.fft_conv(y, hp, N, kind, out=y, options={"plan": plan})
+            torch.cuda.synchronize()
+            assert torch.equal(y, conv.fft_conv(x, hp, N, kind, options={"plan": 4})), plan
 
 
 def test_filter_layout_records_are_ranges_and_can_be_dropped():
