@@ -568,7 +568,10 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 // W^(r0 (i + 64w + 1024g)) (one gather per lane from the natural-order table) times the wave-uniform
 // W^(16 r0 t) and W^(256 r0 r). `tw` holds the N natural-order twiddles followed by the lane-ordered
 // tables of N = 4096.
-template <class T16, bool FWD, int R0, int MINW>
+// H2 (fp16 storage): the pass-1 twiddles of the R0 sub-transforms come rounded to fp16 from a lane-order table
+// (16 KiB per transform, read once for all R0 of them) and are applied with the packed product of the pass-2
+// twiddles, instead of being built R0 times over from start and step values in fp32.
+template <class T16, bool FWD, int R0, int MINW, bool H2 = false>
 __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* in, u32x4_t* out,  // in and out may alias
                                                                      const float2* __restrict__ tw, long long batch,
                                                                      int xcd_log2) {
@@ -606,14 +609,22 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
   T16 mat;
   mat.init(tabs, FWD, tid & 63);
   c32 start[4], step[4];
+  u32x4_t t1h[4];
   typename T16::tw2_t t2[4];
   {
-    const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE / 2);
-    const float4 s0 = ctab[tid], s1 = ctab[256 + tid], q0 = ctab[512 + g], q1 = ctab[516 + g];
-    start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
-    start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);
-    step[0] = make_float2(q0.x, q0.y); step[1] = make_float2(q0.z, q0.w);
-    step[2] = make_float2(q1.x, q1.y); step[3] = make_float2(q1.z, q1.w);
+    if constexpr (H2) {
+      // behind the lane-ordered tables: packed fp16 W^(k1 c), 16-byte entry [map][j][tid], map 1 = columns 64w + 16j + i
+      const u32x4_t* htab = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TABLES) + 1024 + tid;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t1h[j] = htab[256 * j];
+    } else {
+      const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE / 2);
+      const float4 s0 = ctab[tid], s1 = ctab[256 + tid], q0 = ctab[512 + g], q1 = ctab[516 + g];
+      start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
+      start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);
+      step[0] = make_float2(q0.x, q0.y); step[1] = make_float2(q0.z, q0.w);
+      step[2] = make_float2(q1.x, q1.y); step[3] = make_float2(q1.z, q1.w);
+    }
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TW_LANE_ORDER) + (tid & 63);
     const u32x4_t p = ftab[128], q = ftab[192];
     t2[0] = T16::make_tw2(make_float2(__uint_as_float(p.x), __uint_as_float(p.y)));
@@ -631,8 +642,10 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
   for (int r0 = 0; r0 < R0; ++r0) {
     // ---- pass 1: this subsequence's dwords, rows <-> lane groups, 16 columns {64w + 16j + i} per j
     c32 run[4];
+    if constexpr (!H2) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) run[r] = start[r];
+      for (int r = 0; r < 4; ++r) run[r] = start[r];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned a[4];
@@ -653,9 +666,14 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
       const int pos = (4 * w + j + 4 * rot) & 15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const c32 y = twiddle(cr[r], ci[r], run[r]);
-        img_a[((4 * g + r) * 16 + i) * 16 + pos] = T16::pack(y.x, y.y);
-        if (j < 3) run[r] = cmul(run[r], step[r]);
+        if constexpr (H2) {
+          img_a[((4 * g + r) * 16 + i) * 16 + pos] =
+              cmul_h2<!FWD>(pack_h2(cr[r], ci[r]), __builtin_bit_cast(h2_t, (unsigned)t1h[j][r]));
+        } else {
+          const c32 y = twiddle(cr[r], ci[r], run[r]);
+          img_a[((4 * g + r) * 16 + i) * 16 + pos] = T16::pack(y.x, y.y);
+          if (j < 3) run[r] = cmul(run[r], step[r]);
+        }
       }
     }
     __syncthreads();

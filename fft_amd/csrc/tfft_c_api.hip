@@ -336,7 +336,8 @@ int tfft_initialize(int dtype, int n) {
   // 16-bit storage, n >= 256: the table is followed by the lane-ordered tables of the matrix-core kernels
   // (n = 8192, 16384 run 4096-point passes inside: the tables of n = 4096)
   const bool mfma_tables = dtype != TFFT_F32 && n >= 256;
-  const bool conv_tables = mfma_tables && n == tfft::Mfma4096::N;
+  // the fused convolution's packed-fp16 pass-1 twiddles (n = 4096), which the fp16 kernels of n = 8192, 16384 read too
+  const bool conv_tables = mfma_tables && n >= tfft::Mfma4096::N;
   // fp32, n = 8192: the table of the 4096-point transforms this length is built from follows W_n
   const int sub = (dtype == TFFT_F32 && n == 8192) ? 4096 : 0;
   const size_t entries = (size_t)n + sub + (mfma_tables ? tfft::Mfma4096::TABLES : 0) + (conv_tables ? tfft::ConvMfma4096::TABLE : 0);
@@ -349,7 +350,7 @@ int tfft_initialize(int dtype, int n) {
   for (int j = 0; j < sub; ++j) h[n + j] = h[(size_t)j * (n / sub)];
   if (mfma_tables) tfft::mfma_lane_tables(h.data() + n, n < tfft::Mfma4096::N ? n : tfft::Mfma4096::N);
   if (conv_tables) {
-    tfft::conv_mfma4096_tables(h.data() + tfft::ConvMfma4096::OFFSET);
+    tfft::conv_mfma4096_tables(h.data() + n + tfft::Mfma4096::TABLES);
   }
   TFFT_HIP(hipMalloc(reinterpret_cast<void**>(&p.tw), sizeof(float2) * entries));
   hipError_t e = hipMemcpy(p.tw, h.data(), sizeof(float2) * entries, hipMemcpyHostToDevice);
