@@ -11,14 +11,14 @@
 // exactly the B fragment of the inverse's first pass. The product with H (stored in that lane
 // order) is rounded to fp16 and fed straight back into the matrix cores.
 //
-// Pass-1 twiddles W_4096^(k1 c) come from a table of packed fp16 values in lane order (16 per lane and column
-// map, 32 KiB for both maps, read once per workgroup and kept in registers) and are applied with the packed fp16
-// product the pass-2 twiddles use (3 instructions per value, rounding included). The fp32 form they replace -- 4
-// start and 4 step values per lane, W^(k1 (c0 + s)) = W^(k1 c0) (W^(k1 q))^s, 16 KiB of tables -- cost 4 + 1
-// instructions per value plus 12 complex products per pass for the chains: about 120 of the 490 VALU instructions
-// per wave and signal, in a kernel whose on-chip work alone takes longer than its HBM traffic (with the loads or the
-// stores compiled out it ran at 87 % and 82 % of its full time, with neither at 78 %). Rounding the twiddles to fp16
-// moves the result's error against an fp64 convolution from 5.5e-4 to 5.6e-4 (relative L2).
+// Pass-1 twiddles W_4096^(k1 c): 16 packed fp16 values per lane and column map, evaluated once per workgroup with
+// v_sin_f32 / v_cos_f32 (conv_mfma4096_load_tw1), kept in registers and applied with the packed fp16 product the
+// pass-2 twiddles use (3 instructions per value, rounding included). The fp32 form they replace -- 4 start and 4 step
+// values per lane, W^(k1 (c0 + s)) = W^(k1 c0) (W^(k1 q))^s -- cost 4 + 1 instructions per value plus 12 complex
+// products per pass for the chains: about 120 of the 490 VALU instructions per wave and signal, in a kernel whose
+// on-chip work alone takes longer than its HBM traffic (with the loads or the stores compiled out it ran at 87 % and
+// 82 % of its full time, with neither at 78 %). Rounding the twiddles to fp16 moves the result's error against an
+// fp64 convolution from 5.5e-4 to 5.6e-4 (relative L2).
 #pragma once
 #include "fft_mfma_kernel.hpp"
 
@@ -30,7 +30,8 @@ struct ConvMfma4096 {
   static constexpr int OFFSET = Mfma4096::N + Mfma4096::TABLES;
 };
 
-// Host side. 16-byte entry [m][s][tid] = W^(k1 c) as fp16 (cos, -sin) for k1 = 4g + r, r = 0..3, with
+// Host side: the same values as a table, for the fp16 kernels of N = 8192 / 16384 (fft_mfma_big_kernel reads map 1
+// once per transform). 16-byte entry [m][s][tid] = W^(k1 c) as fp16 (cos, -sin) for k1 = 4g + r, r = 0..3, with
 // tid = 64w + 16g + i and column c = 64w + 4i + s (map m = 0: fragments straight from the signal's rows) or
 // c = 16 (4w + s) + i (map m = 1: fragments that are the previous transform's output registers).
 inline void conv_mfma4096_tables(float2* dst) {
@@ -48,11 +49,22 @@ inline void conv_mfma4096_tables(float2* dst) {
       }
 }
 
-// This lane's pass-1 twiddles of column map `map` (see conv_mfma4096_tables).
-__device__ __forceinline__ void conv_mfma4096_load_tw1(const float2* tw, int map, int tid, u32x4_t (&tw1)[4]) {
-  const u32x4_t* tab = reinterpret_cast<const u32x4_t*>(tw + ConvMfma4096::OFFSET) + map * 1024 + tid;
+// This lane's pass-1 twiddles of column map `map` (see conv_mfma4096_tables), evaluated rather than fetched:
+// v_sin_f32 / v_cos_f32 take their argument in turns and (k1 c mod 4096) / 4096 is exact in fp32, so the 32
+// transcendental instructions per map run under the wait for the first signal and the 16 KiB of table per map and
+// workgroup stay out of L2 and the vector cache. (The table itself is still built: the fp16 kernels of
+// N = 8192 / 16384 read map 1 of it.)
+__device__ __forceinline__ void conv_mfma4096_load_tw1(int map, int tid, u32x4_t (&tw1)[4]) {
+  const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) tw1[s] = tab[s * 256];
+  for (int s = 0; s < 4; ++s) {
+    const int c = map == 0 ? 64 * w + 4 * i + s : 16 * (4 * w + s) + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float turns = (float)(((4 * g + r) * c) & 4095) * (1.0f / 4096);
+      tw1[s][r] = __builtin_bit_cast(unsigned, pack_h2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns)));
+    }
+  }
 }
 
 enum : int { kConvMfmaComplex = 0, kConvMfmaRealIn = 1, kConvMfmaRealPair = 2 };
@@ -220,8 +232,8 @@ __global__ __launch_bounds__(256, PERSIST ? 2 : 3) void fft_conv_mfma4096_kernel
 
   // ---- the pass-1 twiddles of both column maps, the matrix fragments
   u32x4_t tw1_g[4], tw1_c[4];
-  conv_mfma4096_load_tw1(tw, 0, tid, tw1_g);
-  conv_mfma4096_load_tw1(tw, 1, tid, tw1_c);
+  conv_mfma4096_load_tw1(0, tid, tw1_g);
+  conv_mfma4096_load_tw1(1, tid, tw1_c);
   h2_t t2[4];
   {
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);
@@ -412,8 +424,8 @@ __global__ __launch_bounds__(256, 3) void fft_conv_mfma4096_dma_kernel(const voi
 #pragma unroll
   for (int t = 0; t < 4; ++t) hreg[t] = hp[(long long)d * 1024 + t * 256 + tid];
   u32x4_t tw1_g[4], tw1_c[4];
-  conv_mfma4096_load_tw1(tw, 0, tid, tw1_g);
-  conv_mfma4096_load_tw1(tw, 1, tid, tw1_c);
+  conv_mfma4096_load_tw1(0, tid, tw1_g);
+  conv_mfma4096_load_tw1(1, tid, tw1_c);
   h2_t t2[4];
   {
     const u32x4_t* ftab = reinterpret_cast<const u32x4_t*>(tw + Mfma4096::N + Mfma4096::TW_LANE_ORDER) + (tid & 63);

@@ -39,6 +39,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "fft_lds_kernel.hpp"
 
@@ -383,9 +384,16 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   if constexpr (INCR) {
     // start [h][tid] = { W^(k1 c0), W^(k1' c0) } for rows s = 4g + 2h and s + 1, c0 = 64w + 4i; step [h][g] = { W^k1, W^k1' }
     const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE);
-    const float4 s0 = ctab[tid], s1 = ctab[256 + tid], q0 = ctab[512 + g], q1 = ctab[516 + g];
-    start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
-    start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);
+    const float4 q0 = ctab[512 + g], q1 = ctab[516 + g];
+    // The start values W^(k1 c0) are evaluated, not fetched: v_sin_f32 / v_cos_f32 take their argument in turns, and
+    // (k1 c0 mod n) / n is exact in fp32, so eight transcendental instructions under the wait for the rows replace the
+    // one table that differs from lane to lane (8 KiB per tile through L2 and the vector cache).
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k1 = (4 * g + r) % R1;
+      const float turns = (float)((k1 * (64 * w + 4 * i)) & (256 * R1 - 1)) * (1.0f / (256 * R1));
+      start[r] = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns));
+    }
     step[0] = make_float2(q0.x, q0.y); step[1] = make_float2(q0.z, q0.w);
     step[2] = make_float2(q1.x, q1.y); step[3] = make_float2(q1.z, q1.w);
   } else if constexpr (R1 > 1) {
@@ -399,6 +407,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   if constexpr (R1 > 1 && R1 < 16) mat1.init_pass1(tabs, FWD, tid & 63);
   typename T16::tw2_t t2[4];
   {
+    // (evaluating these like the start values pays nowhere: N = 256, which has no start values, gains a point x -> y
+    // and loses 3.5 in place; at N = 4096 sixteen transcendentals per lane cost 2 points)
     const u32x4_t p = ftab[128], q = ftab[192];
     t2[0] = T16::make_tw2(make_float2(__uint_as_float(p.x), __uint_as_float(p.y)));
     t2[1] = T16::make_tw2(make_float2(__uint_as_float(p.z), __uint_as_float(p.w)));
@@ -614,14 +624,27 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
   {
     if constexpr (H2) {
       // behind the lane-ordered tables: packed fp16 W^(k1 c), 16-byte entry [map][j][tid], map 1 = columns 64w + 16j + i
+      // (evaluating the sixteen values instead measured level at N = 8192 and 0.4 points slower at N = 16384)
       const u32x4_t* htab = reinterpret_cast<const u32x4_t*>(tabs + Mfma4096::TABLES) + 1024 + tid;
 #pragma unroll
       for (int j = 0; j < 4; ++j) t1h[j] = htab[256 * j];
     } else {
       const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE / 2);
-      const float4 s0 = ctab[tid], s1 = ctab[256 + tid], q0 = ctab[512 + g], q1 = ctab[516 + g];
-      start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
-      start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);
+      const float4 q0 = ctab[512 + g], q1 = ctab[516 + g];
+      if constexpr (std::is_same<T16, MfmaF16>::value) {
+        // (the fp16 A/B form keeps its table: with the evaluation the R0 = 4 instance spills)
+        const float4 s0 = ctab[tid], s1 = ctab[256 + tid];
+        start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
+        start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);
+      } else {
+        // start values W^(k1 (64w + i)): evaluated under the wait for the rows (see fft_mfma4096_kernel; bf16
+        // N = 8192 +0.4 ... 0.8 points, N = 16384 +0.2 ... 0.4)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float turns = (float)(((4 * g + r) * (64 * w + i)) & 4095) * (1.0f / 4096);
+          start[r] = make_float2(__builtin_amdgcn_cosf(turns), -__builtin_amdgcn_sinf(turns));
+        }
+      }
       step[0] = make_float2(q0.x, q0.y); step[1] = make_float2(q0.z, q0.w);
       step[2] = make_float2(q1.x, q1.y); step[3] = make_float2(q1.z, q1.w);
     }
