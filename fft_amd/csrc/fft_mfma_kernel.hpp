@@ -631,8 +631,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma_big_kernel(const u32x4_t* 
     } else {
       const float4* ctab = reinterpret_cast<const float4*>(tabs + Mfma4096::TABLES - Mfma4096::INCR_TABLE / 2);
       const float4 q0 = ctab[512 + g], q1 = ctab[516 + g];
-      if constexpr (std::is_same<T16, MfmaF16>::value) {
-        // (the fp16 A/B form keeps its table: with the evaluation the R0 = 4 instance spills)
+      if constexpr (std::is_same<T16, MfmaF16>::value && R0 == 4) {
+        // (the fp16 A/B form of N = 16384 keeps its table: with the evaluation it spills 36 bytes per lane)
         const float4 s0 = ctab[tid], s1 = ctab[256 + tid];
         start[0] = make_float2(s0.x, s0.y); start[1] = make_float2(s0.z, s0.w);
         start[2] = make_float2(s1.x, s1.y); start[3] = make_float2(s1.z, s1.w);

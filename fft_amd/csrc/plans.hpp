@@ -309,12 +309,15 @@ template <class T16, int R0>
 bool mfma_big_entry_for(bool forward, int mode, KernelEntry* out) {
   // R0 = 4 holds 16 + 16 packed results and inputs per subsequence: 168 VGPRs, three workgroups per CU
   constexpr int MINW = R0 == 2 ? 4 : 3;
-  // fp16: the pass-1 twiddles of the R0 sub-transforms from the packed-fp16 table (default; settled x -> y 76.1 -> 76.8 %
-  // of 8 TB/s at N = 8192, 74.3 -> 75.9 % at N = 16384, in place level and +0.5, relative L2 error 5.3e-4 -> 6.1e-4);
-  // plan 10: built from start and step values in fp32, the form bf16 storage keeps (8 mantissa bits carry no twiddle)
-  constexpr bool kHalfTable = std::is_same<T16, MfmaF16>::value;
-  if (mode == 10 && kHalfTable) {
-    *out = forward ? make_mfma_big_entry<T16, true, R0, MINW>() : make_mfma_big_entry<T16, false, R0, MINW>();
+  // Pass-1 twiddles of the R0 sub-transforms. bf16: built in fp32 from evaluated start values and step values (8
+  // mantissa bits carry no twiddle). fp16 N = 16384: read once per transform from the packed-fp16 table (settled x -> y
+  // 74.3 -> 75.9 % of 8 TB/s over the fp32 form with its start table, relative L2 error 5.3e-4 -> 6.1e-4); fp16
+  // N = 8192: the fp32 form with evaluated start values (78.0 % against 77.3 % for the table, error 5.3e-4). Plan 10 is
+  // the other form of the two for fp16.
+  constexpr bool kFp16 = std::is_same<T16, MfmaF16>::value;
+  constexpr bool kHalfTable = kFp16 && R0 == 4;
+  if (mode == 10 && kFp16) {
+    *out = forward ? make_mfma_big_entry<T16, true, R0, MINW, !kHalfTable>() : make_mfma_big_entry<T16, false, R0, MINW, !kHalfTable>();
     return true;
   }
   if (mode != 0) return false;

@@ -93,7 +93,7 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  *                        the matrix cores by default; there 3 (and 4) are the fp32-VALU kernels and 5-12 other
  *                        forms of the matrix-core kernel: 6 = one workgroup per tile with the twiddle table,
  *                        10 = one workgroup per tile with incrementally built twiddles (fp16 at n = 8192, 16384:
- *                        the default reads them rounded to fp16 from a table, 10 builds them in fp32), 11 = resident grid,
+ *                        the other of the two pass-1 twiddle forms, fp32 chains or an fp16 table), 11 = resident grid,
  *                        12 = plan 10 with one LDS image (n <= 4096); 5, 7 = one LDS image (n = 4096); 8 = split
  *                        bf16 matrix (bf16, n = 4096). A plan a length does not have returns
  *                        TFFT_ERR_UNSUPPORTED. Multi-pass lengths (fp32, n > 16384): 3, 4, 5 = 128 KiB tiles
