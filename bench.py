@@ -192,7 +192,7 @@ def kernel_label(dtype, n, radix):
         if n == 16384:
             return f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward, straight-line>"
         return f"tfft::fft_lds_kernel<Plan{n}, StoreF32, forward>"
-    if 256 <= n <= 4096:
+    if 64 <= n <= 4096:
         return f"tfft::fft_mfma4096_kernel<{dtype}, forward, N={n}>"
     if n > 4096:
         return f"tfft::fft_mfma_big_kernel<{dtype}, forward, N={n}>"

@@ -72,8 +72,12 @@ inline unsigned short mfma_host_half(float f) {  // round to nearest even; |f| <
   return (unsigned short)(sign | ((rounded - 0x38000000u) >> 13));
 }
 
+// n < 256 (64, 128): the tile's rows hold 256 / n whole transforms; pass 2 multiplies by I (x) DFT_q, q = n / 16, and
+// its twiddles are W_n^((k2 mod q) n3). The tables keep their places: the block matrix sits where the pass-1 matrix
+// of the longer lengths does, the twiddles where the W_256 ones do.
 inline void mfma_lane_tables(float2* dst, int n) {
-  const int r1 = n / 256;
+  const int r1 = n < 256 ? 1 : n / 256;
+  const int blk = n < 256 ? n / 16 : r1;  // block size of the block-diagonal matrix
   for (int j = 0; j < 4; ++j)
     for (int rp = 0; rp < 2; ++rp)
       for (int tid = 0; tid < 256; ++tid) {
@@ -104,7 +108,8 @@ inline void mfma_lane_tables(float2* dst, int n) {
       }
       float t2[8];
       for (int r = 0; r < 4; ++r) {
-        const double a = -2.0 * M_PI * (double)((4 * g + r) * i) / 256.0;
+        const double a = n < 256 ? -2.0 * M_PI * (double)(((4 * g + r) % blk) * i) / (double)n
+                                 : -2.0 * M_PI * (double)((4 * g + r) * i) / 256.0;
         t2[2 * r] = (float)cos(a);
         t2[2 * r + 1] = (float)sin(a);
       }
@@ -158,8 +163,8 @@ inline void mfma_lane_tables(float2* dst, int n) {
         for (int jj = 0; jj < 4; ++jj) {
           const int rho = 4 * g + jj;
           float c = 0.f, sn = 0.f;
-          if (i / r1 == rho / r1) {
-            const double a = 2.0 * M_PI * (double)(((i % r1) * (rho % r1)) % r1) / (double)r1;
+          if (i / blk == rho / blk) {
+            const double a = 2.0 * M_PI * (double)(((i % blk) * (rho % blk)) % blk) / (double)blk;
             c = (float)cos(a);
             sn = (float)(d == 0 ? sin(a) : -sin(a));
           }
@@ -330,8 +335,12 @@ constexpr int mfma_out_words() {
 // CONVOUT (N = 4096, one workgroup per transform): the result leaves in the order the fused convolution reads its
 // filter spectra -- 16-byte entry [transform][t][tid] = X[i + 16 (4w + t) + 256 (4g + r)], r = 0..3, which is exactly
 // what a lane holds after pass 3 -- instead of natural order: the filter transform and its re-ordering in one kernel.
+// Q < 16 (with R1 = 1): N = 16 Q = 64 or 128. A row of 256 points holds 16 / Q whole transforms; pass 2 is the
+// block-diagonal I (x) DFT_Q over each transform's Q groups of 16 points, its twiddles are W_N^((k2 mod Q) n3), pass 3
+// is the same DFT_16, and a lane's 16 results are Q-strided points of one transform. The batch need not fill the
+// last row: loads beyond it re-read the last valid 16 bytes, stores beyond it are dropped.
 template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false,
-          bool REPEAT = false, bool CONVOUT = false>
+          bool REPEAT = false, bool CONVOUT = false, int Q = 16>
 __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* in, u32x4_t* out,  // in and out may alias (in-place calls)
                                                                      const float2* __restrict__ tw, long long batch,
                                                                      int xcd_log2, unsigned repeats = 1,
@@ -343,6 +352,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   const bool do_loads = !REPEAT || (io_mask & 1u), do_stores = !REPEAT || (io_mask & 2u);
   static_assert(R1 == 1 || R1 == 2 || R1 == 4 || R1 == 8 || R1 == 16, "N = 256 R1");
   static_assert(!INCR || R1 > 1, "N = 256 has no first pass");
+  static_assert(Q == 16 || ((Q == 4 || Q == 8) && R1 == 1 && !REPEAT && !PERSIST), "N = 64, 128: the one-shot N = 256 form");
   constexpr int OUT_WORDS = mfma_out_words<R1>();
   static_assert(mfma_out_words<16>() == Mfma4096::OUT_IMG, "the convolution kernels share the N = 4096 image");
   __shared__ __attribute__((aligned(16))) unsigned lds[OUT_WORDS + (DOUBLE ? Mfma4096::IMG : 0)];
@@ -351,11 +361,12 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 
   const int tid = threadIdx.x;
   const int w = tid >> 6, g = (tid >> 4) & 3, i = tid & 15;
-  const long long rows_total = batch * R1;          // rows of 256 points
+  const long long units = batch * (4 * Q * R1);     // 16-byte units (four points) of the whole batch
+  const long long rows_total = (units + 63) >> 6;   // rows of 256 points
   const long long tiles = (rows_total + 15) >> 4;
   long long tr = blockIdx.x;
   if (tr >= tiles) return;
-  const float2* const tabs = tw + 256 * R1;
+  const float2* const tabs = tw + 16 * Q * R1;
 
   // ---- rows first: lane (g, i) of wave w loads rows 4G + g, columns 64w + 4i .. 4i+3
   // Rows past the batch (last tile when N < 4096) re-read the tile's last valid row: their results are never
@@ -366,7 +377,14 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     const u32x4_t* src = in + t * 1024 + 16 * w + i;
     const int last = last_row(t);
 #pragma unroll
-    for (int G = 0; G < 4; ++G) rows[G] = __builtin_nontemporal_load(src + min(4 * G + g, last) * 64);
+    for (int G = 0; G < 4; ++G) {
+      if constexpr (Q == 16) {
+        rows[G] = __builtin_nontemporal_load(src + min(4 * G + g, last) * 64);
+      } else {  // the last row may be partly filled
+        const long long at = t * 1024 + 16 * w + i + min(4 * G + g, last) * 64;
+        rows[G] = __builtin_nontemporal_load(in + min(at, units - 1));
+      }
+    }
   };
   // tr is the position in the launch order, tile the 4096 points it stands for (xcd_chunk, fft_lds_kernel.hpp)
   long long tile = xcd_chunk(tr, tiles, xcd_log2);
@@ -405,6 +423,8 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
   mat.init(tabs, FWD, tid & 63);
   T16 mat1 = mat;  // pass 1: DFT_16 when R1 = 16, else I (x) DFT_R1
   if constexpr (R1 > 1 && R1 < 16) mat1.init_pass1(tabs, FWD, tid & 63);
+  T16 mat2 = mat;  // pass 2: DFT_16, or I (x) DFT_Q for N = 64, 128
+  if constexpr (Q < 16) mat2.init_pass1(tabs, FWD, tid & 63);
   typename T16::tw2_t t2[4];
   {
     // (evaluating these like the start values pays nowhere: N = 256, which has no start values, gains a point x -> y
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     mfma_f4 cr, ci;
-    mat.dft16(frag[t], cr, ci);
+    mat2.dft16(frag[t], cr, ci);
     // lane holds Y2[s = 4w + t][k2 = 4g + r][n3 = i]; image 3 row = (k2, s), point n3
     const int rot = (t + 2 * w + (t >> 1)) & 3;
     const int pos = (i + 4 * rot) & 15;
@@ -523,8 +543,10 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
     }
     return;
   }
-  const int slot0 = mfma_out_slot<R1>((i / R1) * (256 * R1) + (i % R1) + R1 * (4 * w) + 16 * R1 * (4 * g));
-  constexpr int R_STEP = 16 * R1 + (R1 == 16 ? 4 : 0);
+  // N = 64, 128: k2 = 4w + t is output ka = k2 mod Q of transform k2 / Q of row i: point 16 Q (k2 / Q) + ka + Q k3
+  const int slot0 = Q < 16 ? mfma_out_slot<1>(i * 256 + 16 * Q * ((4 * w) / Q) + (4 * w) % Q + Q * (4 * g))
+                           : mfma_out_slot<R1>((i / R1) * (256 * R1) + (i % R1) + R1 * (4 * w) + 16 * R1 * (4 * g));
+  constexpr int R_STEP = Q < 16 ? Q : 16 * R1 + (R1 == 16 ? 4 : 0);
   unsigned last[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -557,7 +579,11 @@ __global__ __launch_bounds__(256, MINW) void fft_mfma4096_kernel(const u32x4_t* 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&img_a[mfma_out_slot<R1>(4 * (tid + 256 * q))]);
-    if (do_stores && (R1 == 16 || 4 * q + w <= last_cur)) __builtin_nontemporal_store(v, dst + 256 * q);
+    if constexpr (Q < 16) {
+      if (tile * 1024 + tid + 256 * q < units) __builtin_nontemporal_store(v, dst + 256 * q);
+    } else {
+      if (do_stores && (R1 == 16 || 4 * q + w <= last_cur)) __builtin_nontemporal_store(v, dst + 256 * q);
+    }
   }
   if (!PERSIST || next >= tiles) break;
   __syncthreads();  // the output image is read before the next tile's pass 1 overwrites it

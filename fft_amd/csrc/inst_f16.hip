@@ -6,8 +6,15 @@ namespace tfft {
 // (N = 1024: three passes of 16 points per thread; N = 8192: split exchange) the default is swapped.
 bool lookup_f16(int n, bool forward, int mode, KernelEntry* out) {
   switch (n) {
-    case 64: return entry_for<Plan64, StoreF16, false, Plan64Alt>(forward, mode, out);
-    case 128: return entry_for<Plan128, StoreF16, false, Plan128Alt>(forward, mode, out);
+    case 64:
+      // matrix cores (settled 79-80 % of 8 TB/s against 64-66 % for the VALU kernels, plans 3 and 4)
+      if (mfma_small_entry_for<MfmaF16, 4>(forward, mode, out)) return true;
+      return entry_for<Plan64, StoreF16, false, Plan64Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
+    case 128:
+      // matrix cores: level with the VALU kernels (plans 3 and 4) on a settled device x -> y (79-80 %), 2 points behind
+      // in place, 13 points ahead over a process's first launches (77.5-78.4 % against 63.7-65.9 %)
+      if (mfma_small_entry_for<MfmaF16, 8>(forward, mode, out)) return true;
+      return entry_for<Plan128, StoreF16, false, Plan128Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);
     case 256:
       if (mfma_entry_for<MfmaF16, 1>(forward, mode, out)) return true;
       return entry_for<Plan256, StoreF16, false, Plan256Alt>(forward, mode == 3 ? 0 : mode == 4 ? 3 : -1, out);

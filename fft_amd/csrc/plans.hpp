@@ -166,25 +166,27 @@ KernelEntry make_entry() {
 }
 
 // Matrix-core kernel of fft_mfma_kernel.hpp as a table entry: N = 256 R1, 16 / R1 transforms per workgroup.
-template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST, int R1, bool INCR>
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST, int R1, bool INCR, int Q>
 void launch_mfma4096(const void* in, void* out, const float2* tw, long long batch, long long nchunks,
                      const LaunchShape& shape, hipStream_t stream) {
   // one-shot: one workgroup per tile of 4096 points; resident: the caller's grid (workgroups per CU x CUs)
   const unsigned blocks = PERSIST ? shape.grid : (unsigned)nchunks;
-  fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR><<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(
-      static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw, batch, shape.xcd_log2);
+  fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR, false, false, Q>
+      <<<dim3(blocks), dim3(Mfma4096::WG), 0, stream>>>(static_cast<const u32x4_t*>(in), static_cast<u32x4_t*>(out), tw,
+                                                        batch, shape.xcd_log2);
 }
 
-template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false>
+// Q < 16 (R1 = 1): N = 16 Q = 64 or 128, 4096 / N transforms per workgroup.
+template <class T16, bool FWD, bool DOUBLE, int MINW, bool PERSIST = false, int R1 = 16, bool INCR = false, int Q = 16>
 KernelEntry make_mfma_entry() {
   KernelEntry e;
-  e.fn = reinterpret_cast<const void*>(&fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR>);
-  e.launch = &launch_mfma4096<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR>;
-  e.n = 256 * R1;
+  e.fn = reinterpret_cast<const void*>(&fft_mfma4096_kernel<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR, false, false, Q>);
+  e.launch = &launch_mfma4096<T16, FWD, DOUBLE, MINW, PERSIST, R1, INCR, Q>;
+  e.n = 16 * Q * R1;
   e.threads = Mfma4096::WG;
-  e.tpb = 16 / R1;
+  e.tpb = 256 / (Q * R1);
   e.e = 16;
-  e.radix[0] = R1 == 1 ? 16 : R1;
+  e.radix[0] = R1 == 1 ? Q : R1;
   e.radix[1] = 16;
   e.radix[2] = R1 == 1 ? 1 : 16;
   e.lds_bytes = 4 * (mfma_out_words<R1>() + (DOUBLE ? Mfma4096::IMG : 0));
@@ -244,6 +246,15 @@ bool mfma_entry_for(bool forward, int mode, KernelEntry* out) {
   if (mode == 10) { *out = forward ? make_mfma_entry<T16, true, true, 4, false, R1, INCR>() : make_mfma_entry<T16, false, true, 4, false, R1, INCR>(); return true; }
   if (mode == 12) { *out = forward ? make_mfma_entry<T16, true, false, 8, false, R1, INCR>() : make_mfma_entry<T16, false, false, 8, false, R1, INCR>(); return true; }
   return false;
+}
+
+// N = 64, 128 (Q = 4, 8): the N = 256 kernel with a block-diagonal second pass, one LDS image, eight workgroups per CU.
+// Mode 0 and 12 only; the fp32-VALU kernels of these lengths are modes 3 and 4.
+template <class T16, int Q>
+bool mfma_small_entry_for(bool forward, int mode, KernelEntry* out) {
+  if (mode != 0 && mode != 12) return false;
+  *out = forward ? make_mfma_entry<T16, true, false, 8, false, 1, false, Q>() : make_mfma_entry<T16, false, false, 8, false, 1, false, Q>();
+  return true;
 }
 
 // N = 4096 R0 (8192, 16384), 16-bit storage: fft_mfma_big_kernel, one workgroup per transform.

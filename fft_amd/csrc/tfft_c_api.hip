@@ -333,9 +333,9 @@ int tfft_initialize(int dtype, int n) {
   p.cu_count = prop.multiProcessorCount;
   TFFT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.blocks_per_cu[0], fwd.fn, fwd.threads, 0));
   TFFT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.blocks_per_cu[1], inv.fn, inv.threads, 0));
-  // 16-bit storage, n >= 256: the table is followed by the lane-ordered tables of the matrix-core kernels
+  // 16-bit storage: the table is followed by the lane-ordered tables of the matrix-core kernels
   // (n = 8192, 16384 run 4096-point passes inside: the tables of n = 4096)
-  const bool mfma_tables = dtype != TFFT_F32 && n >= 256;
+  const bool mfma_tables = dtype != TFFT_F32 && n >= 64;
   // the fused convolution's packed-fp16 pass-1 twiddles (n = 4096), which the fp16 kernels of n = 8192, 16384 read too
   const bool conv_tables = mfma_tables && n >= tfft::Mfma4096::N;
   // fp32, n = 8192: the table of the 4096-point transforms this length is built from follows W_n

@@ -57,11 +57,12 @@ int tfft_finalize(int dtype);
  * workspace of your own (tfft_exec_c2c_opt) for calls that should. A multi-pass call made under stream capture
  * is ordered inside its graph only: replays of that graph are not ordered against other users of the
  * library-owned scratch (eager calls, other graphs) -- captured callers use tfft_exec_c2c_static or a workspace.
- * Non-finite inputs: a NaN or infinity stays inside its own transform, with one exception: 16-bit storage at
- * 512 <= n <= 2048 (default plan) runs 2 ... 8 transforms through one matrix product per 4096-point tile, with
+ * Non-finite inputs: a NaN or infinity stays inside its own transform, with two exceptions, both for 16-bit storage
+ * on the default plan. At 512 <= n <= 2048, 2 ... 8 transforms go through one matrix product per 4096-point tile, with
  * explicit zeros between them, so a non-finite value also turns the other transforms of its tile (the 4096 / n
- * consecutive transforms starting at a multiple of 4096 / n) non-finite. tfft_exec_options.plan = 3 (the fp32-VALU
- * kernels) keeps every transform independent. */
+ * consecutive transforms starting at a multiple of 4096 / n) non-finite. At n = 64 and 128 the same holds for the
+ * 256 / n consecutive transforms starting at a multiple of 256 / n (one 256-point row of the tile). tfft_exec_options.plan = 3
+ * (the fp32-VALU kernels) keeps every transform independent. */
 int tfft_exec_c2c(int dtype, int n, int forward, const void* d_in, void* d_out, long long batch,
                   void* stream);
 
@@ -90,7 +91,7 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  * *_opt entry point; NULL there means the defaults. Nothing here is process-wide state.
  *   plan               : 0 = the default kernel of (dtype, n); 3 and up = its alternative kernels (another
  *                        factorisation, workgroup size or LDS exchange form). 16-bit storage at n >= 256 runs on
- *                        the matrix cores by default; there 3 (and 4) are the fp32-VALU kernels and 5-12 other
+ *                        the matrix cores by default (n = 64 and 128 as well: plans 0 and 12; 3 and 4 the VALU kernels); there 3 (and 4) are the fp32-VALU kernels and 5-12 other
  *                        forms of the matrix-core kernel: 6 = one workgroup per tile with the twiddle table,
  *                        10 = one workgroup per tile with incrementally built twiddles (fp16 at n = 8192, 16384:
  *                        the other of the two pass-1 twiddle forms, fp32 chains or an fp16 table), 11 = resident grid,

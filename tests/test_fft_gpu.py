@@ -397,6 +397,37 @@ def test_half_storage_matrix_core_lengths(oracle_mod, n, kind, mode):
 
 
 @pytest.mark.parametrize("kind", ("fp16", "bf16"))
+@pytest.mark.parametrize("n,mode", ((64, 0), (64, 12), (64, 3), (64, 4), (128, 0), (128, 12), (128, 3), (128, 4)))
+def test_half_storage_matrix_core_short_lengths(oracle_mod, n, kind, mode):
+    """16-bit storage, N = 64 and 128 on the matrix cores (modes 0 and 12): the N = 256
+    kernel with a block-diagonal second pass, 4096 / N transforms per workgroup and 256 / N per 256-point row. The
+    other modes are the VALU kernels. Batches that leave the last row and the last tile partly filled, buffers that
+    end right behind the batch (a read past it would fault or show), per-transform errors, both directions, out of
+    place and in place, and nothing written behind the batch."""
+    per_row, per_tile = 256 // n, 4096 // n
+    for batch in (1, per_row + 1, per_tile - 1, per_tile + per_row + 1, 5 * 768 * per_tile + per_tile // 2 + 1):
+        scale = 1.0 / np.sqrt(n) if kind == "fp16" else 1.0
+        x = (synth.uniform_complex(batch, n, seed=n + batch) * scale).astype(np.complex64)
+        for forward in (True, False):
+            for inplace in (False, True):
+                got, stored = run(x, kind, forward, inplace=inplace, options={"plan": mode} if mode else None)
+                ref = oracle_mod.fft(stored, forward)
+                err = oracle_mod.rel_l2(got, ref)
+                assert err <= TOL[kind], f"{kind} n={n} mode={mode} batch={batch} forward={forward} rel_l2={err:.3e}"
+                step = max(1, batch // 97)
+                worst = max(oracle_mod.rel_l2(got[b], ref[b]) for b in list(range(0, batch, step)) + [batch - 1])
+                assert worst <= TOL[kind], (n, mode, batch, forward, worst)
+    batch, extra = per_tile + per_row + 1, 5
+    d = to_device((synth.uniform_complex(batch + extra, n, seed=3) / np.sqrt(n)).astype(np.complex64), kind)
+    out = torch.full_like(d, 123.0)
+    fft_amd.ThunderFFTInitialize(kind, n)
+    fft_amd.ThunderFFT_global(d, out, batch, n, True, options={"plan": mode} if mode else None)
+    torch.cuda.synchronize()
+    assert torch.all(out[batch:] == 123.0)
+    assert not torch.any(out[:batch] == 123.0)
+
+
+@pytest.mark.parametrize("kind", ("fp16", "bf16"))
 @pytest.mark.parametrize("n", (8192, 16384))
 @pytest.mark.parametrize("mode", (0, 3, 4))
 def test_half_storage_matrix_core_long_lengths(oracle_mod, n, kind, mode):
@@ -574,6 +605,37 @@ def test_non_finite_input_stays_in_its_tile(dtype, n):
                 assert not finite[t], f"{dtype} n={n}: the header says transform {t} shares a matrix product with {bad}"
             else:
                 assert finite[t], f"{dtype} n={n} plan={plan}: transform {t} must not see transform {bad}'s NaN"
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_non_finite_input_at_n64_stays_in_its_row(dtype):
+    """n = 64 with 16-bit storage runs on the matrix cores with four transforms per 256-point row sharing a
+    block-diagonal product: the header says a non-finite value reaches exactly the four consecutive transforms that
+    start at a multiple of four, and nothing else; plan 3 (the VALU kernel) keeps it to the one transform. At
+    n = 128 the product is shared between the two transforms of a pair."""
+    n, batch, bad = 64, 203, 133  # the batch does not fill its last row or its last tile
+    dt = TORCH_DT[dtype]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = ((torch.rand(batch, n, 2, device="cuda", generator=g) * 2 - 1) / n ** 0.5).to(dt)
+    x[bad, 17, 1] = float("inf")
+    fft_amd.ThunderFFTInitialize(dtype, n)
+    for plan in (0, 3):
+        y = torch.empty_like(x)
+        fft_amd.ThunderFFT_global(x, y, batch, n, True, options={"plan": plan} if plan else None)
+        torch.cuda.synchronize()
+        finite = torch.isfinite(y.float()).all(dim=(1, 2)).cpu().numpy()
+        for t in range(batch):
+            hit = t == bad or (plan == 0 and t // 4 == bad // 4)
+            assert finite[t] != hit, (dtype, plan, t)
+    fft_amd.ThunderFFTInitialize(dtype, 128)
+    x = ((torch.rand(9, 128, 2, device="cuda", generator=g) * 2 - 1) / 128 ** 0.5).to(dt)
+    x[4, 3, 0] = float("nan")
+    for plan, hits in ((3, {4}), (0, {4, 5})):
+        y = torch.empty_like(x)
+        fft_amd.ThunderFFT_global(x, y, 9, 128, True, options={"plan": plan} if plan else None)
+        torch.cuda.synchronize()
+        finite = torch.isfinite(y.float()).all(dim=(1, 2)).cpu().numpy()
+        assert {t for t in range(9) if not finite[t]} == hits, (dtype, plan)
 
 
 def test_grid_options_rejected_where_the_grid_is_the_batch():
