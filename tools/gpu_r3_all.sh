@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything this round's profiles/ files come from, in one GPU call; every step under its own time limit.
+# Everything the profiles/r03_* files come from, in one GPU call; every step under its own time limit.
 set -u
 mkdir -p gpurun_out
 timeout -k 10 600 bash tools/gpu_r3_profiles.sh || exit 1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The tracked profiles of this round: rocprofv3 kernel trace + stats and FETCH_SIZE / WRITE_SIZE of bench.py, one
+# The tracked profiles (profiles/r03_*): rocprofv3 kernel trace + stats and FETCH_SIZE / WRITE_SIZE of bench.py, one
 # configuration per run. 16-bit configurations get 50 warm-up and 100 timed launches (the matrix-core kernels
 # need tens of milliseconds of sustained work to reach their rate).
 set -u

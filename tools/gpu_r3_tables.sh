@@ -1,5 +1,5 @@
 #!/bin/bash
-# The C++ bench's tables with the final kernels of round 3 (text output of bench/tfft_bench): fp32 sweep with the hipFFT
+# The C++ bench's tables with the current kernels (text output of bench/tfft_bench): fp32 sweep with the hipFFT
 # and copy rows (e2e protocol and in-kernel repeats), in place, the 16-bit sweeps, the multi-pass lengths, and the SQ
 # counters of the fp16 N = 4096 kernel. --warmup / --runs as the binary defaults (the reference's 1 + 10) unless SETTLED=1.
 set -u
