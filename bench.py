@@ -349,7 +349,8 @@ def main(argv=None):
 
     # The same kernel with its butterflies and LDS exchanges compiled out (tfft_bench_access_pattern, pattern 1: the
     # rows are loaded and stored in the transform's access pattern, the output is meaningless): what this workgroup
-    # shape can stream at all. Its own entry point, outside the timed region; fp32 lengths that have the build only.
+    # shape can stream at all. Its own entry point, outside and behind the timed region -- so on a device that has
+    # settled, where the N = 4096 transform itself reads 76-77 %; fp32 lengths that have the build only.
     shape_ms = None
     # (N = 8192 has no such build of its default kernel, fft_dit_kernel: the figure would be another kernel's.)
     if not stub and args.dtype == "fp32" and n <= 16384 and n != 8192 and batch > 0:
