@@ -393,7 +393,7 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            # fp32 storage: fp32 VALU arithmetic; 16-bit storage at N >= 256: 16-bit matrix-core operands, fp32 accumulation
+            # fp32 storage: fp32 VALU arithmetic; 16-bit storage: 16-bit matrix-core operands, fp32 accumulation
             "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.dtype],
             "data": "stub (no GPU work: launcher self-test)" if stub else "synthetic",
             "config": {

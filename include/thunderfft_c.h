@@ -90,8 +90,8 @@ int tfft_get_plan_info(int dtype, int n, tfft_plan_info* info);
  * and launch shapes kept for A/B timing. Fill with tfft_exec_options_init, change what is needed, pass to a
  * *_opt entry point; NULL there means the defaults. Nothing here is process-wide state.
  *   plan               : 0 = the default kernel of (dtype, n); 3 and up = its alternative kernels (another
- *                        factorisation, workgroup size or LDS exchange form). 16-bit storage at n >= 256 runs on
- *                        the matrix cores by default (n = 64 and 128 as well: plans 0 and 12; 3 and 4 the VALU kernels); there 3 (and 4) are the fp32-VALU kernels and 5-12 other
+ *                        factorisation, workgroup size or LDS exchange form). 16-bit storage runs on
+ *                        the matrix cores by default at every length (n = 64 and 128: plans 0 and 12; 3 and 4 the VALU kernels); there 3 (and 4) are the fp32-VALU kernels and 5-12 other
  *                        forms of the matrix-core kernel: 6 = one workgroup per tile with the twiddle table,
  *                        10 = one workgroup per tile with incrementally built twiddles (fp16 at n = 8192, 16384:
  *                        the other of the two pass-1 twiddle forms, fp32 chains or an fp16 table), 11 = resident grid,
